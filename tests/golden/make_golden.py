@@ -1,0 +1,348 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REAL REFERENCE.
+
+Run in the build container only (the reference lives at /root/reference and never
+travels):  ``PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py``
+
+Only inputs and expected outputs are stored (data, no reference source).  Weights are
+not stored: both sides rebuild them from ``oracle.idccrn_oracle.synth_tensor(name,
+shape, seed)``.  While generating, every oracle function is checked against the
+reference output, so a fixture is only written when the oracle is pinned.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("IDCCRN_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import idccrn_oracle as O  # noqa: E402
+
+import model.complex_progress as R_cp  # noqa: E402  (reference)
+import model.pvae_module as R_pm  # noqa: E402  (reference)
+import model.sisnr_loss as R_sisnr  # noqa: E402
+import model.nsvae_loss as R_nl  # noqa: E402
+import model.pretrain_pvaes_loss as R_pl  # noqa: E402
+import model.causal_netconfig as R_cnc  # noqa: E402
+import model.net_config as R_nc  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+NFFT, HOP, WIN = 512, 100, 400
+
+
+def rnd(seed, *shape, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((scale * g.standard_normal(shape)).astype("float32"))
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check(name, got, want, tol=2e-5):
+    e = relerr(got, want)
+    status = "ok" if e <= tol else "FAIL"
+    print(f"  [{status}] oracle vs reference  {name:40s} rel={e:.2e}")
+    assert e <= tol, name
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def load_synth(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = O.synth_state_dict(shapes, seed)
+    module.load_state_dict(sd, strict=True)
+    module.eval()
+    return sd
+
+
+def fix_bn_flags(module, flag):
+    for m in module.modules():
+        if isinstance(m, R_cp.ComplexBatchNormal):
+            m.init_flag = flag
+
+
+# ----------------------------------------------------------------------------- ops
+def gen_ops():
+    print("== unit fixtures")
+    # STFT / ISTFT
+    x = rnd(1, 2, 3200, scale=0.1)
+    st = R_pm.STFT(NFFT, HOP, WIN, "cpu")
+    ist = R_pm.ISTFT(NFFT, HOP, WIN, "cpu")
+    X = st(x)
+    check("stft", O.stft(x, NFFT, HOP, WIN), X)
+    Y = rnd(2, 2, 257, 33, 2)
+    y = ist(torch.complex(Y[..., 0], Y[..., 1]))
+    check("istft", O.istft(Y, NFFT, HOP, WIN), y)
+    save("op_stft", x=x, X=X, Y=Y, y=y)
+
+    # complex conv (causal and not), complex transposed conv
+    for causal in (True, False):
+        cin, cout, F, T = 3, 8, 17, 9
+        xin = rnd(3, 2, cin, F, T, 2)
+        pad = (2, 1) if causal else (2, 0)
+        cls = R_cp.causal_complex_conv2d if causal else R_cp.ComplexConv2d
+        m = cls(cin, cout, (5, 2), (2, 1), pad)
+        sd = load_synth(m, 11)
+        y = m(xin)
+        args = (sd["conv_re.weight"], sd["conv_re.bias"], sd["conv_im.weight"], sd["conv_im.bias"], (2, 1), pad, causal)
+        check(f"cconv causal={causal}", O.complex_conv2d(xin, *args), y)
+        check(f"cconv naive causal={causal}", O.complex_conv2d_naive(xin, *args), y)
+        save(f"op_cconv_{'causal' if causal else 'plain'}", x=xin, y=y, cin=cin, cout=cout, seed=11)
+
+        cin, cout, F, T = 6, 4, 9, 9
+        xin = rnd(4, 2, cin, F, T, 2)
+        cls = R_cp.causal_ComplexConvTranspose2d if causal else R_cp.ComplexConvTranspose2d
+        m = cls(cin, cout, (5, 2), (2, 1), (2, 0))
+        sd = load_synth(m, 12)
+        y = m(xin)
+        args = (sd["tconv_re.weight"], sd["tconv_re.bias"], sd["tconv_im.weight"], sd["tconv_im.bias"], (2, 1), (2, 0), causal)
+        check(f"cconvT causal={causal}", O.complex_conv_transpose2d(xin, *args), y)
+        check(f"cconvT naive causal={causal}", O.complex_conv_transpose2d_naive(xin, *args), y)
+        save(f"op_cconvt_{'causal' if causal else 'plain'}", x=xin, y=y, cin=cin, cout=cout, seed=12)
+
+    # complex batch norm: train (first call + momentum call) and eval
+    C = 8
+    xin = rnd(5, 3, C, 9, 7, 2) * 1.5 + 0.3
+    bn = R_cp.ComplexBatchNormal(C, 0, 0)
+    sd = load_synth(bn, 13)
+    y_eval = bn(xin, train=False)
+    g = lambda k: sd[k]
+    check("cbn eval", O.cbn_whiten_affine(xin, g("running_mean_real"), g("running_mean_imag"), g("Vrr"), g("Vri"), g("Vii"),
+                                          g("gamma_rr"), g("gamma_ri"), g("gamma_ii"), g("beta_r"), g("beta_i")), y_eval)
+    bn.init_flag = True
+    y_train = bn(xin, train=True)
+    stats = O.cbn_batch_stats(xin)
+    check("cbn train", O.cbn_whiten_affine(xin, *stats, g("gamma_rr"), g("gamma_ri"), g("gamma_ii"), g("beta_r"), g("beta_i")), y_train)
+    first = {k: bn.state_dict()[k].clone() for k in ("running_mean_real", "running_mean_imag", "Vrr", "Vri", "Vii")}
+    for k, s in zip(("running_mean_real", "running_mean_imag", "Vrr", "Vri", "Vii"), stats):
+        check(f"cbn running[{k}] first call", s, first[k])
+    xin2 = rnd(6, 3, C, 9, 7, 2) * 0.7 - 0.2
+    bn(xin2, train=True)
+    second = {k: bn.state_dict()[k].clone() for k in first}
+    stats2 = O.cbn_batch_stats(xin2)
+    for k, s1, s2 in zip(first, stats, stats2):
+        check(f"cbn running[{k}] momentum", 0.9 * s1 + 0.1 * s2, second[k])
+    save("op_cbn", x=xin, x2=xin2, y_eval=y_eval, y_train=y_train, seed=13, C=C,
+         **{"first_" + k: v for k, v in first.items()}, **{"second_" + k: v for k, v in second.items()})
+
+    # PReLU
+    pr = torch.nn.PReLU()
+    pr.weight.fill_(0.2)
+    check("prelu", O.prelu(xin, pr.weight), pr(xin))
+
+    # complex LSTM
+    T, B, I, H = 7, 3, 20, 16
+    xin = rnd(7, T, B, I, 2)
+    m = R_cp.ComplexLSTM(I, H, "cpu", num_layers=2)
+    sd = load_synth(m, 14)
+    y = m(xin)
+    check("complex lstm", O.complex_lstm(xin, sd, "", 2), y)
+    save("op_clstm", x=xin, y=y, seed=14, I=I, H=H)
+
+    # complex dense
+    m = R_cp.ComplexDense(16, 40)
+    sd = load_synth(m, 15)
+    xin = rnd(8, 21, 16, 2)
+    y = m(xin)
+    check("complex dense", O.complex_dense(xin, sd["linear_read.weight"], sd["linear_read.bias"],
+                                           sd["linear_imag.weight"], sd["linear_imag.bias"]), y)
+    save("op_cdense", x=xin, y=y, seed=15)
+
+    # SI-SNR known answer (model/sisnr_loss.py:27-30) and random
+    src = torch.tensor([1, 2, 3, 4, 5, 1, 2, 3, 4, 5]).view(2, 5).float()
+    est = torch.tensor([[1.5, 2.5, 3.5, 4.5, 5.5], [1.5, 2.5, 3.5, 4.5, 5.5]])
+    ka = R_sisnr.si_snr(src, est)
+    print("  si_snr known answer:", float(ka))
+    check("si_snr known answer", O.si_snr(src, est), ka)
+    check("si_snr matmul form", O.si_snr_matmul_form(src, est), ka)
+    s2, e2 = rnd(9, 4, 1600, scale=0.1), rnd(10, 4, 1600, scale=0.1)
+    e2 = s2 + 0.3 * e2
+    r2 = R_sisnr.si_snr(s2, e2)
+    check("si_snr random", O.si_snr(s2, e2), r2)
+    save("op_sisnr", src=src, est=est, known=ka, s2=s2, e2=e2, r2=r2)
+
+    # recon loss
+    P = rnd(11, 3, 257, 9, 2)
+    Or = rnd(12, 3, 257, 9, 2)
+    so, es = rnd(13, 3, 800, scale=0.1), rnd(14, 3, 800, scale=0.1)
+    L = R_nl.ete_train_se_loss([0.3, 0.5, 1.0])
+    want = L.final_ete_loss(torch.complex(P[..., 0], P[..., 1]), Or, so, es)
+    got = O.multiple_recon_loss(P, Or, so, es, [0.3, 0.5, 1.0])
+    for n, a, b in zip(("final", "cpx", "mag", "sisnr"), got, want):
+        check("recon loss " + n, a, b)
+    save("op_recon", P=P, O=Or, source=so, est=es, want=torch.stack(list(want)))
+
+    # reparameterisation (randn_like injected) and KLs
+    B, T, H, ns = 2, 5, 8, 3
+    miu, ls, dl = rnd(15, B, T, H, 2), rnd(16, B, T, H, 2, scale=0.3), rnd(17, B, T, H, 2, scale=0.8)
+    eps_r, eps_i = rnd(18, B, ns, T, H), rnd(19, B, ns, T, H)
+    enc = R_pm.pvae_dccrn_encoder_skip_prepare(O.net_params(True, 4), True, "cpu", H, NFFT, HOP, WIN, ns)
+    draws = [eps_r, eps_i]
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: draws.pop(0)
+    try:
+        z = enc.reparameterization(miu, ls, dl, ns)
+    finally:
+        torch.randn_like = orig
+    check("reparameterization", O.reparameterization(miu, ls, dl, ns, eps_r, eps_i), z)
+    miu2, ls2, dl2 = rnd(20, B, T, H, 2), rnd(21, B, T, H, 2, scale=0.3), rnd(22, B, T, H, 2, scale=0.8)
+    pl = R_pl.complex_standard_vae_loss(torch.ones(1), 1.0, 0.0, 'multiple', 'real_imag', [1, 1, 0], ns)
+    kl_p = pl.cal_kl_arbi_prior(miu, miu2, ls, ls2, dl, dl2)
+    check("kl pretrain", O.complex_kl(miu, miu2, ls, ls2, dl, dl2, 1e-9).mean(), kl_p)
+    nl = R_nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.5, H, ns, 2, 'original', 'False', [], 'both')
+    kl_n = nl.cal_kl(miu, miu2, ls, ls2, dl, dl2, None)
+    check("kl nsvae", O.complex_kl(miu, miu2, ls, ls2, dl, dl2, 1e-10), kl_n)
+    miu3, ls3, dl3 = rnd(23, B, T, H, 2), rnd(24, B, T, H, 2, scale=0.3), rnd(25, B, T, H, 2, scale=0.8)
+    miu4, ls4, dl4 = rnd(26, B, T, H, 2), rnd(27, B, T, H, 2, scale=0.3), rnd(28, B, T, H, 2, scale=0.8)
+    want = nl.final_nsvae_loss(miu, miu2, miu3, miu4, ls, ls2, ls3, ls4, dl, dl2, dl3, dl4, None, None, None, None, None)
+    got = O.nsvae_loss(miu, miu2, miu3, miu4, ls, ls2, ls3, ls4, dl, dl2, dl3, dl4, 1.0, 1.0, 0.5, 2)
+    for n, a, b in zip(("final", "kl", "kl_clean", "kl_noise", "dis_s", "dis_n"), got, want[:6]):
+        check("nsvae loss " + n, a, b)
+    save("op_vae", miu=miu, ls=ls, dl=dl, miu2=miu2, ls2=ls2, dl2=dl2, miu3=miu3, ls3=ls3, dl3=dl3,
+         miu4=miu4, ls4=ls4, dl4=dl4, eps_r=eps_r, eps_i=eps_i, z=z, kl_pretrain=kl_p, kl_nsvae=kl_n,
+         nsvae=torch.stack([torch.as_tensor(w).float() for w in want[:6]]))
+
+
+# ----------------------------------------------------------------------------- models
+def gen_dccrn(tag, base, B, L, seed, train, causal=True, full_outputs=True):
+    print(f"== DCCRN_ {tag}: base={base} B={B} L={L} train={train} causal={causal}")
+    np_ref = (R_cnc if causal else R_nc).get_net_params()
+    np_ = O.net_params(causal, base)
+    if base == 32:
+        for k in ("encoder_channels", "decoder_channels", "lstm_dim", "dense", "encoder_paddings"):
+            assert [tuple(v) if isinstance(v, (list, tuple)) else v for v in np_ref[k]] == \
+                   [tuple(v) if isinstance(v, (list, tuple)) else v for v in np_[k]], k
+    skip = [0, 1, 2, 3, 4, 5]
+    m = R_pm.DCCRN_(NFFT, HOP, np_, causal, "cpu", WIN, skip, "mask", False, None, None)
+    sd = load_synth(m, seed)
+    x = rnd(seed + 100, B, L, scale=0.1)
+    fix_bn_flags(m, True)
+    clean, pred = m(x, train=train)
+    bs = O.BNState()
+    o_clean, o_pred, o_lat = O.dccrn_forward(x, sd, np_, causal, NFFT, HOP, WIN, skip, "mask", train, bs)
+    check("waveform", o_clean, clean, 1e-4)
+    check("predict stft", o_pred, torch.view_as_real(pred), 1e-4)
+    out = dict(x=x, clean=clean, seed=seed, base=base, train=int(train), causal=int(causal))
+    pr = torch.view_as_real(pred)
+    if full_outputs:
+        out["pred"] = pr
+    else:
+        out["pred_sub"] = pr[:, ::8, ::16]
+        out["pred_l2"] = pr.double().norm()
+        out["pred_mean"] = pr.double().mean()
+    if train:
+        after = m.state_dict()
+        for k in after:
+            if k.endswith(("running_mean_real", "running_mean_imag", "Vrr", "Vri", "Vii")) and ".bn." in k:
+                out["bn:" + k] = after[k]
+    else:
+        out["latent"] = m.std_DCCRN.latent
+        check("latent", o_lat, m.std_DCCRN.latent, 1e-4)
+    clean_ref = rnd(seed + 200, B, clean.shape[1], scale=0.1)
+    L_ = R_nl.ete_train_se_loss([0.0, 0.0, 1.0])
+    loss = L_.final_ete_loss(pred, m.stft(clean_ref), clean_ref, clean)
+    out["clean_ref"] = clean_ref
+    out["loss"] = torch.stack(list(loss))
+    save(f"dccrn_{tag}", **out)
+
+
+def gen_vae(tag, base, zdim, B, L, ns, seed, train):
+    print(f"== VAE {tag}: base={base} zdim={zdim} B={B} L={L} ns={ns} train={train}")
+    np_ = O.net_params(True, base)
+    skip = [0, 1, 2, 3, 4, 5]
+    x = rnd(seed + 100, B, L, scale=0.1)
+    T = 1 + L // HOP
+    # ---- CVAE encoder/decoder (skip_prepare), real_imag
+    enc = R_pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cpu", zdim, NFFT, HOP, WIN, ns)
+    dec = R_pm.pvae_dccrn_decoder_skip_prepare(np_, True, "cpu", ns, zdim, NFFT, HOP, WIN, "real_imag", skip)
+    sd_e, sd_d = load_synth(enc, seed), load_synth(dec, seed + 1)
+    eps = [rnd(seed + 300, B, ns, T, zdim), rnd(seed + 301, B, ns, T, zdim)]
+    draws = list(eps)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: draws.pop(0)
+    try:
+        fix_bn_flags(enc, True)
+        z, miu, ls, dl, skiper, C, F, stft_x = enc(x, train=train)
+    finally:
+        torch.randn_like = orig
+    fix_bn_flags(dec, True)
+    recon, pred = dec(stft_x, z, skiper, C, F, train=train)
+    oe = O.vae_encoder_forward(x, sd_e, np_, True, zdim, NFFT, HOP, WIN, ns, 1, eps, train)
+    check("cvae z", oe["z_speech"], z, 1e-4)
+    check("cvae miu", oe["miu_speech"], miu, 1e-4)
+    o_rec, o_pred = O.vae_decoder_forward(oe["stft_x"], oe["z_speech"], oe["skiper"], C, F, sd_d, np_, True, ns,
+                                          NFFT, HOP, WIN, "real_imag", skip, "zero", True, train)
+    check("cvae recon", o_rec, recon, 1e-4)
+    xr = x[:, :recon.shape[1]].repeat_interleave(ns, dim=0)
+    sx = stft_x.repeat_interleave(ns, dim=0)
+    pl = R_pl.complex_standard_vae_loss(torch.ones(1), 1.0, 0.0, 'multiple', 'real_imag', [1.0, 1.0, 0.0], ns)
+    lo = pl.cal_loss(xr, recon, sx, pred, miu, ls, dl, z, 5)
+    ol = O.cvae_elbo(xr, o_rec, sx, o_pred, oe["miu_speech"], oe["log_sigma_speech"], oe["delta_speech"], 1.0, [1.0, 1.0, 0.0])
+    check("cvae elbo", ol[0], lo[0], 1e-4)
+    check("cvae kl", ol[2], lo[2], 1e-4)
+    save(f"vae_cvae_{tag}", x=x, eps_r=eps[0], eps_i=eps[1], z=z, miu=miu, log_sigma=ls, delta=dl,
+         skip5=skiper[5], skip0_sub=skiper[0][:, ::4, ::8, ::4], recon=recon, pred_sub=torch.view_as_real(pred)[:, ::4, ::4],
+         elbo=torch.stack([torch.as_tensor(v).float() for v in (lo[0], lo[1], lo[2], lo[4], lo[5], lo[6])]),
+         seed=seed, base=base, zdim=zdim, ns=ns, train=int(train))
+
+    # ---- NSVAE twophase encoder (latent_num=2) + twophase decoder (mask, pad='sig')
+    enc2 = R_pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cpu", zdim, NFFT, HOP, WIN, ns, 2)
+    dec2 = R_pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, "cpu", ns, zdim, NFFT, HOP, WIN, "mask", True, skip, False)
+    sd_e2, sd_d2 = load_synth(enc2, seed + 2), load_synth(dec2, seed + 3)
+    eps2 = [rnd(seed + 310 + i, B, ns, T, zdim) for i in range(4)]
+    draws = list(eps2)
+    torch.randn_like = lambda t, *a, **k: draws.pop(0)
+    try:
+        fix_bn_flags(enc2, True)
+        r = enc2(x, train=train)
+    finally:
+        torch.randn_like = orig
+    z_s, miu_s, ls_s, dl_s, z_n, miu_n, ls_n, dl_n, skiper2, C, F, stft_x2 = r
+    fix_bn_flags(dec2, True)
+    recon2, pred2 = dec2(stft_x2, z_s, skiper2, C, F, train=train, pad='sig')
+    oe2 = O.vae_encoder_forward(x, sd_e2, np_, True, zdim, NFFT, HOP, WIN, ns, 2, eps2, train)
+    check("nsvae z_speech", oe2["z_speech"], z_s, 1e-4)
+    check("nsvae z_noise", oe2["z_noise"], z_n, 1e-4)
+    o_rec2, o_pred2 = O.vae_decoder_forward(oe2["stft_x"], oe2["z_speech"], oe2["skiper"], C, F, sd_d2, np_, True, ns,
+                                            NFFT, HOP, WIN, "mask", skip, "sig", True, train)
+    check("twophase recon", o_rec2, recon2, 1e-4)
+    tl = R_nl.two_phase_loss([0, 0, 1], 1.0, zdim, 1)
+    l2 = tl.phase_2_loss(pred2, sx, xr, recon2, None, None, None, None)
+    save(f"vae_nsvae_{tag}", x=x, **{f"eps{i}": e for i, e in enumerate(eps2)}, z_speech=z_s, z_noise=z_n,
+         miu_speech=miu_s, miu_noise=miu_n, log_sigma_speech=ls_s, log_sigma_noise=ls_n, delta_speech=dl_s,
+         delta_noise=dl_n, recon=recon2, pred_sub=torch.view_as_real(pred2)[:, ::4, ::4],
+         phase2=torch.stack([torch.as_tensor(v).float() for v in l2[:4]]),
+         seed=seed, base=base, zdim=zdim, ns=ns, train=int(train))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops", "mini", "full"]
+    if "ops" in which:
+        gen_ops()
+    if "mini" in which:
+        gen_dccrn("mini_eval", 4, 2, 1600, 21, train=False)
+        gen_dccrn("mini_train", 4, 2, 1600, 22, train=True)
+        gen_dccrn("mini_noncausal_eval", 4, 2, 1600, 23, train=False, causal=False)
+        gen_vae("mini_eval", 4, 16, 2, 1600, 3, 31, train=False)
+        gen_vae("mini_train", 4, 16, 2, 1600, 2, 41, train=True)
+    if "full" in which:
+        torch.set_num_threads(os.cpu_count())
+        gen_dccrn("full_eval", 32, 2, 64000, 51, train=False, full_outputs=False)
