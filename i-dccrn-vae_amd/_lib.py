@@ -1,0 +1,99 @@
+"""ctypes binding of libidccrn_hip.so (the C ABI declared in include/idccrn_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no
+CPU fallback: if the shared object is missing or a symbol is absent the import of the
+operators fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libidccrn_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "idccrn_hip.h")
+
+_lib = None
+
+
+class IdvError(RuntimeError):
+    pass
+
+
+def declared_symbols() -> list:
+    """Every function name declared in include/idccrn_hip.h."""
+    with open(HEADER_PATH) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(idv_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IdvError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP hot path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name in declared_symbols():
+            if not hasattr(_lib, name):
+                if os.environ.get("IDV_DEV_PARTIAL_LIB"):
+                    continue
+                raise IdvError(f"libidccrn_hip.so does not export {name}")
+            if name == "idv_clstm_work_floats":
+                _lib.idv_clstm_work_floats.restype = ctypes.c_longlong
+    return _lib
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_longlong
+_F = ctypes.c_float
+_D = ctypes.c_double
+
+
+def call(name: str, *args):
+    """Call an idv_* entry; tensors become device pointers, python numbers keep their C type
+    via the wrappers p()/i()/f()/d()/ll().  Raises IdvError on a non-zero status."""
+    fn = getattr(lib(), name)
+    rc = fn(*args)
+    if rc != 0:
+        raise IdvError(f"{name} failed with status {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")
+
+
+class _TensorPtr(ctypes.c_void_p):
+    """c_void_p that keeps its tensor alive until the (asynchronous, stream-ordered) call is issued."""
+
+
+def p(t) -> ctypes.c_void_p:
+    """Device pointer of a tensor (None -> NULL).  The returned object holds a reference to the
+    tensor, so temporaries (``x.contiguous()``, ``x.to(dev)``) survive until the launch is queued;
+    after that the caching allocator's stream ordering protects the memory."""
+    if t is None:
+        return _P(None)
+    r = _TensorPtr(t.data_ptr())
+    r._keep = t
+    return r
+
+
+def i(v) -> ctypes.c_int:
+    return _I(int(v))
+
+
+def ll(v) -> ctypes.c_longlong:
+    return _L(int(v))
+
+
+def f(v) -> ctypes.c_float:
+    return _F(float(v))
+
+
+def d(v) -> ctypes.c_double:
+    return _D(float(v))
+
+
+def stream_ptr() -> ctypes.c_void_p:
+    import torch
+    return _P(torch.cuda.current_stream().cuda_stream)

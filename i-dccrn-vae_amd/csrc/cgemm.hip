@@ -1,0 +1,81 @@
+// Host-side configuration choice + launch of cgemm_kernel, and the C-ABI entry points built on it.
+#include "cgemm.hpp"
+#include "../../include/idccrn_hip.h"
+
+namespace {
+
+template <int MODE, int WM, int WN, int MT_W, int FO_T, int JC_W, int CCK, bool SWAP, bool STATS>
+int launch_cfg(const CgemmArgs& a, hipStream_t st) {
+    using G = CgemmGeom<MODE, FO_T>;
+    constexpr int JT = 32 * JC_W * WN;
+    constexpr int NE = CCK * G::FR * (JT + 2);
+    constexpr size_t smem = 2 * NE * sizeof(float);
+    const int rows = (MODE == IDV_TCONV) ? a.Fin : a.Fout;          // TCONV tiles over input rows m
+    dim3 grid((a.J + JT - 1) / JT, (rows + FO_T - 1) / FO_T, ((a.M + 31) / 32 + WM * MT_W - 1) / (WM * MT_W));
+    auto k = cgemm_kernel<MODE, WM, WN, MT_W, FO_T, JC_W, CCK, SWAP, STATS>;
+    if (smem > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return IDV_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), smem, st, a);
+    return idv_launch_status();
+}
+
+inline int waste(int n, int t) { return ((n + t - 1) / t) * t - n; }
+
+template <bool STATS>
+int launch_conv(const CgemmArgs& a, int mode, hipStream_t st) {
+    const int CC = 2 * (a.C0 + a.C1);
+    const int rows = (mode == IDV_TCONV) ? a.Fin : a.Fout;
+    const bool fo5 = waste(rows, 5) <= waste(rows, 3);
+    if (mode == IDV_CONV) {
+        if (CC % 4 != 0) return launch_cfg<IDV_CONV, 2, 2, 1, 3, 3, 2, false, STATS>(a, st);
+        if (fo5) return launch_cfg<IDV_CONV, 2, 2, 1, 5, 2, 4, false, STATS>(a, st);
+        return launch_cfg<IDV_CONV, 2, 2, 1, 3, 3, 4, false, STATS>(a, st);
+    }
+    if (CC % 4 != 0) return IDV_EINVAL;
+    if (a.M <= 32) return launch_cfg<IDV_TCONV, 1, 4, 1, 3, 1, 4, false, STATS>(a, st);
+    if (fo5) return launch_cfg<IDV_TCONV, 2, 2, 1, 5, 1, 4, false, STATS>(a, st);
+    return launch_cfg<IDV_TCONV, 2, 2, 1, 3, 2, 4, false, STATS>(a, st);
+}
+
+}  // namespace
+
+extern "C" int idv_cconv_cck(int cin_used) { return ((2 * cin_used) % 4 == 0) ? 4 : 2; }
+
+extern "C" int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div,
+                               const float* wfrag, const float* bias, const float* prelu_slope, float* out,
+                               double* stats, int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp,
+                               int t_valid_out, void* stream) {
+    if (!x0 || !wfrag || !bias || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    if (C1 > 0 && (!x1 || x1_div < 1)) return IDV_EINVAL;
+    if (tshift != 0 && tshift != -1) return IDV_EINVAL;
+    CgemmArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1;
+    a.Fin = Fin;
+    a.Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.Jp1 = Jp1; a.x1_div = x1_div < 1 ? 1 : x1_div;
+    a.wfrag = wfrag; a.bias = bias; a.slope = prelu_slope; a.out = out;
+    a.M = 2 * Cout; a.Mtiles = (a.M + 31) / 32; a.cplx_rows = 1; a.Cout = Cout;
+    a.tshift = tshift; a.t_valid = t_valid_out; a.stats = stats; a.ldo = 0; a.nB = B;
+    if (Jp < a.J) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int mode = transposed ? IDV_TCONV : IDV_CONV;
+    return stats ? launch_conv<true>(a, mode, st) : launch_conv<false>(a, mode, st);
+}
+
+extern "C" int idv_pw_gemm(const float* x, int K, const float* wfrag, const float* bias, const float* prelu_slope,
+                           float* out, int M, int B, int Tp, int Jp, int t_valid, int swap, int ldo, void* stream) {
+    if (!x || !wfrag || !bias || !out || K <= 0 || (K & 1) || M <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    CgemmArgs a{};
+    a.x0 = x; a.x1 = nullptr; a.C0 = K / 2; a.C1 = 0;
+    a.Fin = 1; a.Fout = 1;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.Jp1 = 0; a.x1_div = 1;
+    a.wfrag = wfrag; a.bias = bias; a.slope = prelu_slope; a.out = out;
+    a.M = M; a.Mtiles = (M + 31) / 32; a.cplx_rows = 0; a.Cout = M;
+    a.tshift = 0; a.t_valid = t_valid; a.stats = nullptr; a.ldo = ldo; a.nB = B;
+    if (Jp < a.J) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (swap) return launch_cfg<IDV_PW, 2, 2, 2, 1, 2, 8, true, false>(a, st);
+    return launch_cfg<IDV_PW, 2, 2, 2, 1, 2, 8, false, false>(a, st);
+}

@@ -1,0 +1,282 @@
+// cgemm: the one MFMA contraction kernel behind every dense op on the hot path.
+//
+//   out[m][fo][j] = bias[m] + sum_{cc,kf,kt} W'[m][cc][kf][kt] * x[cc][fi(fo,kf)][j + kt + tshift]
+//
+// A complex Conv2d / ConvTranspose2d of the reference (model/complex_progress.py:8-36,
+// :222-279: four real convolutions + stack) is ONE such real contraction over the planar
+// channel index cc = 2*ci + ri with the block weight [[Wr,-Wi],[Wi,Wr]] (rows m = 2*co + ro),
+// built once by pack.hip; eval-mode ComplexBatchNormal (complex_progress.py:161-209) is
+// folded into W'/bias there, PReLU (pvae_module.py:58,82) runs in the epilogue, and in train
+// mode the epilogue emits the five per-channel moments the batch statistics need.
+// The same kernel in PW mode (1x1, k-pairs = plane pairs) is the LSTM input projection,
+// ComplexDense (complex_progress.py:77-89), and the DFT / inverse-DFT of STFT / ISTFT.
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32).  The two k of one instruction are the two time
+// taps (kt = 0,1) of one (cc, kf): lanes 0-31 read patch column j, lanes 32-63 column j+1 of
+// the SAME LDS row, so the im2col expansion costs nothing and is bank-conflict free.
+// Weights stream from L2 in pre-swizzled fragment order (one coalesced 256 B load per
+// fragment, no LDS); the input patch (CCK planes x FR rows x JT+2 columns) is staged
+// global -> registers -> LDS, double buffered, one barrier per K chunk.
+#pragma once
+#include "common.hpp"
+
+#ifndef IDV_WAVES_PER_SIMD
+#define IDV_WAVES_PER_SIMD 1
+#endif
+
+enum { IDV_CONV = 0, IDV_TCONV = 1, IDV_PW = 2 };
+
+struct CgemmArgs {
+    const float* x0;      // first source, planar [2][C0][Fin][Jp] (PW: K planes of stride Jp)
+    const float* x1;      // optional second source (skip connection), planar [2][C1][Fin][Jp1]
+    int C0, C1;           // complex channels taken from x0 / x1 (PW: C0 = K/2, C1 = 0)
+    int Fin, Fout;        // input / output rows (PW: 1 / 1)
+    int J, Jp, Tp;        // columns, row stride, columns per utterance
+    int Jp1, x1_div;      // x1 row stride; x1 column j maps to utterance (b / x1_div)
+    const float* wfrag;   // [Mtiles][KS][64] fragment-ordered weights
+    const float* bias;    // [Mtiles*32]
+    const float* slope;   // PReLU slope (device scalar) or nullptr
+    float* out;           // planar [M planes][Fout][Jp] or, SWAP, row-major [pos][ldo]
+    int M;                // valid rows
+    int Mtiles;           // allocated 32-row tiles in wfrag (multiple of the block's tiles)
+    int cplx_rows;        // 1: row m = 2*co + ro -> plane ro*Cout + co ; 0: plane = m
+    int Cout;
+    int tshift;           // -1: taps (x[t-1], x[t])   0: taps (x[t], x[t+1])
+    int t_valid;          // outputs at tp in [1, t_valid] are kept, everything else is zero
+    double* stats;        // train mode: [Cout][5] sums (r, i, rr, ii, ri) or nullptr
+    int ldo;              // SWAP: row stride of out; rows are ordered (tp-1)*B + b
+    int nB;               // SWAP: utterances (B)
+};
+
+template <int MODE, int FO_T>
+struct CgemmGeom {
+    static constexpr int KF = (MODE == IDV_PW) ? 1 : 5;
+    static constexpr int FR = (MODE == IDV_CONV) ? 2 * FO_T + 3 : (MODE == IDV_TCONV ? FO_T + 2 : 1);
+    static constexpr int ROWS = (MODE == IDV_TCONV) ? 2 * FO_T : FO_T;   // output row tiles per j chunk
+};
+
+// WM x WN waves; each wave owns MT_W row tiles (32 rows) and ROWS*JC_W column tiles (32 cols).
+template <int MODE, int WM, int WN, int MT_W, int FO_T, int JC_W, int CCK, bool SWAP, bool STATS>
+__global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(const CgemmArgs a) {
+    using G = CgemmGeom<MODE, FO_T>;
+    constexpr int NT = WM * WN * 64;
+    constexpr int KF = G::KF, FR = G::FR, ROWS = G::ROWS;
+    constexpr int JT = 32 * JC_W * WN;
+    constexpr int PS = JT + 2;                    // patch row: columns j0-1 .. j0+JT
+    constexpr int NE = CCK * FR * PS;             // patch elements per K chunk
+    constexpr int NLD = (NE + NT - 1) / NT;
+    constexpr int NCOL = ROWS * JC_W;
+    constexpr int KSC = (MODE == IDV_PW) ? CCK / 2 : CCK * KF;   // MFMA k-steps per chunk
+    static_assert(MODE != IDV_PW || (CCK % 2 == 0), "PW chunks are plane pairs");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // block coordinates: x = j tile, y = row (f) tile, z = m tile
+    const int j0 = blockIdx.x * JT;
+    const int ft = blockIdx.y;
+    const int mt0 = (blockIdx.z * WM + wm) * MT_W;          // first 32-row tile of this wave
+    const int fo0 = ft * FO_T;                              // CONV: first output row; TCONV: first m
+    const int fbase = (MODE == IDV_CONV) ? 2 * fo0 - 2 : (MODE == IDV_TCONV ? fo0 - 1 : 0);
+
+    const int CC = 2 * (a.C0 + a.C1);
+    const int nchunk = (CC + CCK - 1) / CCK;                 // wfrag is zero padded to whole chunks
+    const int KS = (MODE == IDV_PW) ? nchunk * CCK / 2 : nchunk * CCK * KF;   // k-steps per row tile
+
+    f32x16 acc[MT_W][NCOL];
+#pragma unroll
+    for (int i = 0; i < MT_W; ++i)
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+    float stg[NLD];
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * NT;
+            float v = 0.f;
+            if (e < NE) {
+                const int row = e / PS, col = e - row * PS;
+                const int ccl = row / FR, fr = row - ccl * FR;
+                const int cc = chunk * CCK + ccl;
+                const int fi = fbase + fr;
+                const int j = j0 - 1 + col;
+                if (cc < CC && fi >= 0 && fi < a.Fin && j >= 0 && j < a.J) {
+                    if (MODE == IDV_PW) {
+                        v = a.x0[(size_t)cc * a.Jp + j];
+                    } else {
+                        const int ci = cc >> 1, ri = cc & 1;
+                        if (ci < a.C0) {
+                            v = a.x0[((size_t)(ri * a.C0 + ci) * a.Fin + fi) * a.Jp + j];
+                        } else {
+                            int js = j;
+                            if (a.x1_div > 1) {
+                                const int b = j / a.Tp;
+                                js = j - (b - b / a.x1_div) * a.Tp;
+                            }
+                            v = a.x1[((size_t)(ri * a.C1 + (ci - a.C0)) * a.Fin + fi) * a.Jp1 + js];
+                        }
+                    }
+                }
+            }
+            stg[i] = v;
+        }
+    };
+    auto stage_store = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * NT;
+            if (e < NE) dst[e] = stg[i];
+        }
+    };
+
+    const float* wbase = a.wfrag + (size_t)mt0 * KS * 64 + lane;
+    const int bcol = wn * (JC_W * 32) + (lane & 31) + (lane >> 5) + 1 + a.tshift;
+
+    stage_load(0);
+    stage_store(smem);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const float* P = smem + (chunk & 1) * NE;
+        if (chunk + 1 < nchunk) stage_load(chunk + 1);
+
+        const float* wch = wbase + (size_t)chunk * KSC * 64;
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) {
+            float af[MT_W];
+#pragma unroll
+            for (int i = 0; i < MT_W; ++i) af[i] = wch[((size_t)i * KS + ks) * 64];
+            const int ccl = (MODE == IDV_PW) ? 2 * ks : ks / KF;
+            const int kf = (MODE == IDV_PW) ? 0 : ks % KF;
+#pragma unroll
+            for (int rt = 0; rt < ROWS; ++rt) {
+                int fr;
+                if (MODE == IDV_CONV) {
+                    fr = 2 * rt + kf;
+                } else if (MODE == IDV_TCONV) {
+                    if ((rt & 1) != (kf & 1)) continue;       // even rows take even taps, odd rows odd taps
+                    fr = (rt >> 1) + 2 - (kf >> 1);
+                } else {
+                    fr = 0;
+                }
+#pragma unroll
+                for (int jc = 0; jc < JC_W; ++jc) {
+                    float bf;
+                    if (MODE == IDV_PW)
+                        bf = P[(ccl + (lane >> 5)) * PS + wn * (JC_W * 32) + jc * 32 + (lane & 31) + 1];
+                    else
+                        bf = P[(ccl * FR + fr) * PS + bcol + jc * 32];
+#pragma unroll
+                    for (int i = 0; i < MT_W; ++i) {
+                        if (SWAP)
+                            acc[i][rt * JC_W + jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf, af[i], acc[i][rt * JC_W + jc], 0, 0, 0);
+                        else
+                            acc[i][rt * JC_W + jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf, acc[i][rt * JC_W + jc], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (chunk + 1 < nchunk) stage_store(smem + ((chunk + 1) & 1) * NE);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const float slope = a.slope ? *a.slope : 1.0f;
+    const bool has_act = a.slope != nullptr;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    if (!SWAP) {
+        // rows of the tile live in registers, column j = lane & 31
+#pragma unroll
+        for (int i = 0; i < MT_W; ++i) {
+            const int mt = mt0 + i;
+            // train-mode moments: registers (2q, 2q+1) hold (real, imag) of one channel
+            float st[STATS ? 8 : 1][5];
+            if (STATS) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) st[q][s] = 0.f;
+            }
+#pragma unroll
+            for (int jc = 0; jc < JC_W; ++jc) {
+                const int j = j0 + wn * (JC_W * 32) + jc * 32 + l31;
+                const int tp = j % a.Tp;
+                const bool keep = (tp >= 1) && (tp <= a.t_valid);
+                const bool inb = j < a.J;
+#pragma unroll
+                for (int rt = 0; rt < ROWS; ++rt) {
+                    const int fo = (MODE == IDV_TCONV) ? 2 * (fo0 + (rt >> 1)) + (rt & 1) : fo0 + rt;
+                    if (fo >= a.Fout) continue;
+                    const f32x16 v = acc[i][rt * JC_W + jc];
+                    float y[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float t = v[r] + ((m < a.M) ? a.bias[m] : 0.f);
+                        if (has_act) t = t >= 0.f ? t : slope * t;
+                        y[r] = keep ? t : 0.f;
+                        if (m < a.M && inb) {
+                            const int plane = a.cplx_rows ? ((m & 1) * a.Cout + (m >> 1)) : m;
+                            a.out[((size_t)plane * a.Fout + fo) * a.Jp + j] = y[r];
+                        }
+                    }
+                    if (STATS) {
+                        if (inb && keep) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const float yr = y[2 * q], yi = y[2 * q + 1];
+                                st[q][0] += yr;
+                                st[q][1] += yi;
+                                st[q][2] += yr * yr;
+                                st[q][3] += yi * yi;
+                                st[q][4] += yr * yi;
+                            }
+                        }
+                    }
+                }
+            }
+            if (STATS) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int m = mt * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * half;
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) {
+                        float t = st[q][s];
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                        if (l31 == 0 && m < a.M) atomicAdd(&a.stats[(size_t)(m >> 1) * 5 + s], (double)t);
+                    }
+                }
+            }
+        }
+    } else {
+        // SWAP: rows of the tile (registers) are columns j, lane & 31 is the output row m
+#pragma unroll
+        for (int i = 0; i < MT_W; ++i) {
+            const int m = (mt0 + i) * 32 + l31;
+            const float bm = (m < a.M) ? a.bias[m] : 0.f;
+#pragma unroll
+            for (int jc = 0; jc < JC_W; ++jc) {
+                const f32x16 v = acc[i][jc];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + wn * (JC_W * 32) + jc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (j >= a.J || m >= a.M) continue;
+                    const int b = j / a.Tp, tp = j - b * a.Tp;
+                    if (tp < 1 || tp > a.t_valid) continue;
+                    float y = v[r] + bm;
+                    if (has_act) y = y >= 0.f ? y : slope * y;
+                    a.out[((size_t)(tp - 1) * a.nB + b) * a.ldo + m] = y;
+                }
+            }
+        }
+    }
+}

@@ -1,0 +1,38 @@
+// Shared device helpers for the I-DCCRN-VAE MI355X (gfx950) kernels.
+//
+// Activation layout used by every kernel in this library ("planar-J"):
+//   act[ri][C][F][Jp]   fp32, ri = 0 real / 1 imag plane
+//   column j = b * Tp + tp,  Tp = T_stft + 1,  tp = t + 1
+//   tp == 0 is a zero guard column in front of every utterance (it provides the causal
+//   x[t-1] = 0 tap without a branch), columns tp > T_valid are zero as well.
+//   Jp (row stride) = J rounded up to 4; buffers carry IDV_SLACK floats in front and behind.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IDV_SLACK 256
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define IDV_OK 0
+#define IDV_EINVAL (-1)
+#define IDV_ELAUNCH (-2)
+
+static inline int idv_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? IDV_OK : IDV_ELAUNCH;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

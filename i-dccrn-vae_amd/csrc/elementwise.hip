@@ -1,0 +1,287 @@
+// Bandwidth-bound kernels of the hot path: STFT framing, ISTFT overlap-add, mask application,
+// train-mode complex batch-norm finalise/apply, reparameterisation.
+#include "common.hpp"
+#include "../../include/idccrn_hip.h"
+
+namespace {
+
+// frames[k][j] = xp[b][hop*t + left + k],  xp = reflect-pad(x, n_fft/2)   (torch.stft, center=True)
+// one block per (b, 32 frames); the signal segment is staged in LDS, writes are coalesced along j.
+constexpr int FR_TT = 32;
+__global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restrict__ x, int B, int L, int n_fft, int win,
+                                                          int hop, int T, float* __restrict__ frames, int Tp, int Jp) {
+    extern __shared__ float seg[];
+    const int b = blockIdx.y, t0 = blockIdx.x * FR_TT;
+    const int left = (n_fft - win) / 2, half = n_fft / 2;
+    const int nt = min(FR_TT, T - t0);
+    const int seglen = hop * (nt - 1) + win;
+    const long long s0 = (long long)hop * t0 + left - half;      // original-signal index of seg[0]
+    for (int e = threadIdx.x; e < seglen; e += blockDim.x) {
+        long long s = s0 + e;
+        if (s < 0) s = -s;
+        if (s >= L) s = 2LL * (L - 1) - s;
+        seg[e] = (s >= 0 && s < L) ? x[(size_t)b * L + s] : 0.f;
+    }
+    __syncthreads();
+    const int tl = threadIdx.x & 31, kq = threadIdx.x >> 5;       // 32 frames x 8 k-lanes
+    if (tl < nt) {
+        const size_t col = (size_t)b * Tp + t0 + tl + 1;
+        for (int k = kq; k < win; k += 8) frames[(size_t)k * Jp + col] = seg[hop * tl + k];
+    }
+    // guard column tp == 0 of this utterance
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < win; k += blockDim.x) frames[(size_t)k * Jp + (size_t)b * Tp] = 0.f;
+}
+
+// y[b][s] = env_inv[s + half] * sum_t frames[n = s + half - hop*t - left][b*Tp + t + 1]
+__global__ void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ env_inv, int B, int n_fft,
+                                 int win, int hop, int T, int Tp, int Jp, float* __restrict__ y) {
+    const int Lout = hop * (T - 1);
+    const int left = (n_fft - win) / 2, half = n_fft / 2;
+    const long long n = (long long)B * Lout;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / Lout), s = (int)(idx % Lout);
+        const int p = s + half - left;                 // position relative to the window start of frame 0
+        int t_hi = p / hop;
+        if (t_hi > T - 1) t_hi = T - 1;
+        int t_lo = (p - win + hop) / hop;              // smallest t with p - hop*t < win
+        if (p - win + 1 <= 0) t_lo = 0;
+        if (t_lo < 0) t_lo = 0;
+        float acc = 0.f;
+        for (int t = t_lo; t <= t_hi; ++t) {
+            const int k = p - hop * t;
+            if (k >= 0 && k < win) acc += frames[(size_t)k * Jp + (size_t)b * Tp + t + 1];
+        }
+        y[idx] = acc * env_inv[s + half];
+    }
+}
+
+// predict = X * M * tanh|M| / |M|   (== |X| tanh|M| exp(j(angle X + angle M)), pvae_module.py:224-234)
+__global__ void mask_apply_kernel(const float* __restrict__ mask, const float* __restrict__ X, int x_div, int JpX,
+                                  float* __restrict__ pred, float* __restrict__ pred_c, int F, int B, int T, int Tp, int Jp) {
+    const long long n = (long long)B * F * T;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % T);
+        const int f = (int)((idx / T) % F);
+        const int b = (int)(idx / ((long long)T * F));
+        const size_t jm = (size_t)f * Jp + (size_t)b * Tp + t + 1;
+        const size_t jx = (size_t)f * JpX + (size_t)(b / x_div) * Tp + t + 1;
+        const float mr = mask[jm], mi = mask[(size_t)F * Jp + jm];
+        const float xr = X[jx], xi = X[(size_t)F * JpX + jx];
+        const float mm = sqrtf(mr * mr + mi * mi);
+        const float g = tanhf(mm);
+        // unit phasor of the mask exactly as the reference builds it: (m / (tanh|m| + 1e-8)) normalised
+        float ur, ui;
+        if (mm > 0.f) {
+            const float inv = 1.0f / mm;
+            ur = mr * inv; ui = mi * inv;
+        } else {
+            ur = 1.f; ui = 0.f;     // atan2(0, 0) = 0
+        }
+        const float pr = g * (xr * ur - xi * ui), pi = g * (xr * ui + xi * ur);
+        pred[jm] = pr;
+        pred[(size_t)F * Jp + jm] = pi;
+        if (pred_c) {
+            pred_c[idx * 2] = pr;
+            pred_c[idx * 2 + 1] = pi;
+        }
+    }
+}
+
+__global__ void planar_to_complex_kernel(const float* __restrict__ act, float* __restrict__ out_c, int F, int B, int T,
+                                         int Tp, int Jp) {
+    const long long n = (long long)B * F * T;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % T);
+        const int f = (int)((idx / T) % F);
+        const int b = (int)(idx / ((long long)T * F));
+        const size_t j = (size_t)f * Jp + (size_t)b * Tp + t + 1;
+        out_c[idx * 2] = act[j];
+        out_c[idx * 2 + 1] = act[(size_t)F * Jp + j];
+    }
+}
+
+// sums (double) -> moments, running buffers, fold.  One thread per channel.
+__global__ void cbn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ g_rr,
+                                    const float* __restrict__ g_ri, const float* __restrict__ g_ii,
+                                    const float* __restrict__ b_r, const float* __restrict__ b_i, int C, int first_call,
+                                    float momentum, float* __restrict__ run_r, float* __restrict__ run_i,
+                                    float* __restrict__ rVrr, float* __restrict__ rVri, float* __restrict__ rVii,
+                                    float* __restrict__ moments, float* __restrict__ fold) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double* s = stats + (size_t)c * 5;
+    const double mr = s[0] / count, mi = s[1] / count;
+    const float eps = 1e-5f;
+    const float mu_r = (float)mr, mu_i = (float)mi;
+    const float Vrr = (float)(s[2] / count - mr * mr) + eps;
+    const float Vii = (float)(s[3] / count - mi * mi) + eps;
+    const float Vri = (float)(s[4] / count - mr * mi);
+    if (moments) {
+        moments[c] = mu_r; moments[C + c] = mu_i; moments[2 * C + c] = Vrr; moments[3 * C + c] = Vri; moments[4 * C + c] = Vii;
+    }
+    if (run_r) {
+        if (first_call) {
+            run_r[c] = mu_r; run_i[c] = mu_i; rVrr[c] = Vrr; rVri[c] = Vri; rVii[c] = Vii;
+        } else {
+            const float a = momentum, bq = 1.0f - momentum;
+            run_r[c] = a * run_r[c] + bq * mu_r;
+            run_i[c] = a * run_i[c] + bq * mu_i;
+            rVrr[c] = a * rVrr[c] + bq * Vrr;
+            rVri[c] = a * rVri[c] + bq * Vri;
+            rVii[c] = a * rVii[c] + bq * Vii;
+        }
+    }
+    float delta = Vrr * Vii - Vri * Vri + eps;
+    delta = fmaxf(delta, 1e-8f);
+    const float sq = sqrtf(delta);
+    const float tt = sqrtf(Vrr + Vii + 2.f * sq + eps);
+    const float inv = 1.0f / (sq * tt + eps);
+    const float Wrr = (Vii + sq) * inv, Wii = (Vrr + sq) * inv, Wri = -Vri * inv;
+    const float Zrr = g_rr[c] * Wrr + g_ri[c] * Wri;
+    const float Zri = g_rr[c] * Wri + g_ri[c] * Wii;
+    const float Zir = g_ri[c] * Wrr + g_ii[c] * Wri;
+    const float Zii = g_ri[c] * Wri + g_ii[c] * Wii;
+    float* z = fold + (size_t)c * 6;
+    z[0] = Zrr; z[1] = Zri; z[2] = Zir; z[3] = Zii;
+    z[4] = b_r[c] - (Zrr * mu_r + Zri * mu_i);
+    z[5] = b_i[c] - (Zir * mu_r + Zii * mu_i);
+}
+
+// in place: (r, i) <- PReLU(Z (r, i) + s) on kept columns; grid = (column tiles, C*F rows)
+__global__ void cbn_apply_prelu_kernel(float* __restrict__ act, const float* __restrict__ fold,
+                                       const float* __restrict__ slope_p, int C, int F, int B, int Tp, int Jp, int t_valid) {
+    const int row = blockIdx.y;            // c*F + f
+    const int c = row / F;
+    const float* z = fold + (size_t)c * 6;
+    const float Zrr = z[0], Zri = z[1], Zir = z[2], Zii = z[3], sr = z[4], si = z[5];
+    const float slope = slope_p ? *slope_p : 1.0f;
+    float* pr = act + (size_t)row * Jp;
+    float* pi = act + ((size_t)C * F + row) * Jp;
+    const int J = B * Tp;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < J; j += gridDim.x * blockDim.x) {
+        const int tp = j % Tp;
+        if (tp < 1 || tp > t_valid) continue;
+        const float r = pr[j], im = pi[j];
+        float yr = Zrr * r + Zri * im + sr;
+        float yi = Zir * r + Zii * im + si;
+        yr = yr >= 0.f ? yr : slope * yr;
+        yi = yi >= 0.f ? yi : slope * yi;
+        pr[j] = yr;
+        pi[j] = yi;
+    }
+}
+
+// reparameterisation, pvae_module.py:1832-1886.  One thread per (b, t, h); loops over the ns samples.
+__global__ void reparam_kernel(const float* __restrict__ lat, int Hl, int off_miu, int off_ls, int off_dl, int zdim,
+                               const float* __restrict__ eps_r, const float* __restrict__ eps_i, int ns, int B, int T,
+                               int Tp, int Jp, float* __restrict__ z, int Jpz) {
+    const long long n = (long long)B * zdim * T;
+    const float e = 1e-6f;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % T);
+        const int h = (int)((idx / T) % zdim);
+        const int b = (int)(idx / ((long long)T * zdim));
+        const size_t j = (size_t)b * Tp + t + 1;
+        const float* re = lat;
+        const float* im = lat + (size_t)Hl * Jp;
+        const float mr = re[(size_t)(off_miu + h) * Jp + j], mi = im[(size_t)(off_miu + h) * Jp + j];
+        const float sg = expf(re[(size_t)(off_ls + h) * Jp + j]);
+        float dr = re[(size_t)(off_dl + h) * Jp + j], di = im[(size_t)(off_dl + h) * Jp + j];
+        float a = sqrtf(dr * dr + di * di + e);
+        const float scale = sg * 0.99f / (a + e);
+        if (a >= sg - 1e-3f) { dr *= scale; di *= scale; }
+        a = sqrtf(dr * dr + di * di + e);
+        const float den = sqrtf(2.f * (sg + dr) + e);
+        const float k_rr = (sg + dr) / (den + e);
+        const float k_ir = di / (den + e);
+        const float k_ii = sqrtf(sg * sg - a * a + e) / (den + e);
+        for (int s = 0; s < ns; ++s) {
+            const size_t ei = (((size_t)b * ns + s) * T + t) * zdim + h;
+            const float er = eps_r[ei], eim = eps_i[ei];
+            const size_t jz = (size_t)(b * ns + s) * Tp + t + 1;
+            z[(size_t)h * Jpz + jz] = mr + k_rr * er;
+            z[((size_t)zdim + h) * Jpz + jz] = mi + k_ir * er + k_ii * eim;
+        }
+    }
+}
+
+__global__ void zero_guard_kernel(float* __restrict__ act, int planes, int B, int Tp, int Jp) {
+    const long long n = (long long)planes * B;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x)
+        act[(size_t)(idx / B) * Jp + (size_t)(idx % B) * Tp] = 0.f;
+}
+
+inline int grid_for(long long n, int bs = 256) {
+    long long g = (n + bs - 1) / bs;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int idv_stft_frames(const float* x, int B, int L, int n_fft, int win, int hop, int T, float* frames, int Tp,
+                               int Jp, void* stream) {
+    if (!x || !frames || B <= 0 || L <= n_fft / 2 || T != 1 + L / hop || Tp < T + 1 || Jp < B * Tp) return IDV_EINVAL;
+    const size_t smem = (size_t)(hop * (FR_TT - 1) + win) * sizeof(float);
+    hipLaunchKernelGGL(stft_frames_kernel, dim3((T + FR_TT - 1) / FR_TT, B), dim3(256), smem, (hipStream_t)stream, x, B, L,
+                       n_fft, win, hop, T, frames, Tp, Jp);
+    return idv_launch_status();
+}
+
+extern "C" int idv_istft_ola(const float* frames, const float* env_inv, int B, int n_fft, int win, int hop, int T, int Tp,
+                             int Jp, float* y, void* stream) {
+    if (!frames || !env_inv || !y || B <= 0 || T < 2 || Tp < T + 1) return IDV_EINVAL;
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(grid_for((long long)B * hop * (T - 1))), dim3(256), 0, (hipStream_t)stream,
+                       frames, env_inv, B, n_fft, win, hop, T, Tp, Jp, y);
+    return idv_launch_status();
+}
+
+extern "C" int idv_mask_apply(const float* mask, const float* X, int x_div, int JpX, float* pred, float* pred_c, int F,
+                              int B, int T, int Tp, int Jp, void* stream) {
+    if (!mask || !X || !pred || x_div < 1 || F <= 0 || B <= 0 || T <= 0) return IDV_EINVAL;
+    hipLaunchKernelGGL(zero_guard_kernel, dim3(grid_for(2LL * F * B)), dim3(256), 0, (hipStream_t)stream, pred, 2 * F, B, Tp, Jp);
+    hipLaunchKernelGGL(mask_apply_kernel, dim3(grid_for((long long)B * F * T)), dim3(256), 0, (hipStream_t)stream, mask, X,
+                       x_div, JpX, pred, pred_c, F, B, T, Tp, Jp);
+    return idv_launch_status();
+}
+
+extern "C" int idv_planar_to_complex(const float* act, float* out_c, int F, int B, int T, int Tp, int Jp, void* stream) {
+    if (!act || !out_c || F <= 0 || B <= 0 || T <= 0) return IDV_EINVAL;
+    hipLaunchKernelGGL(planar_to_complex_kernel, dim3(grid_for((long long)B * F * T)), dim3(256), 0, (hipStream_t)stream, act,
+                       out_c, F, B, T, Tp, Jp);
+    return idv_launch_status();
+}
+
+extern "C" int idv_cbn_finalize(const double* stats, double count, const float* gamma_rr, const float* gamma_ri,
+                                const float* gamma_ii, const float* beta_r, const float* beta_i, int C, int first_call,
+                                float momentum, float* running_mean_r, float* running_mean_i, float* Vrr, float* Vri,
+                                float* Vii, float* moments, float* fold, void* stream) {
+    if (!stats || count <= 0 || !gamma_rr || !gamma_ri || !gamma_ii || !beta_r || !beta_i || !fold || C <= 0) return IDV_EINVAL;
+    if (running_mean_r && (!running_mean_i || !Vrr || !Vri || !Vii)) return IDV_EINVAL;
+    hipLaunchKernelGGL(cbn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, count, gamma_rr,
+                       gamma_ri, gamma_ii, beta_r, beta_i, C, first_call, momentum, running_mean_r, running_mean_i, Vrr, Vri,
+                       Vii, moments, fold);
+    return idv_launch_status();
+}
+
+extern "C" int idv_cbn_apply_prelu(float* act, const float* fold, const float* prelu_slope, int C, int F, int B, int Tp,
+                                   int Jp, int t_valid, void* stream) {
+    if (!act || !fold || C <= 0 || F <= 0 || B <= 0) return IDV_EINVAL;
+    const int J = B * Tp;
+    int gx = (J + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(cbn_apply_prelu_kernel, dim3(gx, C * F), dim3(256), 0, (hipStream_t)stream, act, fold, prelu_slope, C,
+                       F, B, Tp, Jp, t_valid);
+    return idv_launch_status();
+}
+
+extern "C" int idv_reparam(const float* lat, int Hl, int off_miu, int off_ls, int off_dl, int zdim, const float* eps_r,
+                           const float* eps_i, int ns, int B, int T, int Tp, int Jp, float* z, int Jpz, void* stream) {
+    if (!lat || !eps_r || !eps_i || !z || zdim <= 0 || ns <= 0 || B <= 0 || T <= 0) return IDV_EINVAL;
+    if (off_miu + zdim > Hl || off_ls + zdim > Hl || off_dl + zdim > Hl || Jpz < B * ns * Tp) return IDV_EINVAL;
+    hipLaunchKernelGGL(zero_guard_kernel, dim3(grid_for(2LL * zdim * B * ns)), dim3(256), 0, (hipStream_t)stream, z, 2 * zdim,
+                       B * ns, Tp, Jpz);
+    hipLaunchKernelGGL(reparam_kernel, dim3(grid_for((long long)B * zdim * T)), dim3(256), 0, (hipStream_t)stream, lat, Hl,
+                       off_miu, off_ls, off_dl, zdim, eps_r, eps_i, ns, B, T, Tp, Jp, z, Jpz);
+    return idv_launch_status();
+}

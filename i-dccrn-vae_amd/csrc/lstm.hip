@@ -1,0 +1,342 @@
+// ComplexLSTM.forward (model/complex_progress.py:50-74) on MI355X.
+//
+// The four real 2-layer LSTM passes (lstm_re/lstm_im applied to x_r/x_i) are four independent "runs"
+// r = 2*z + s (z: 0 = real input, 1 = imag input; s: 0 = lstm_re weights, 1 = lstm_im weights):
+//   real = run0 - run3,  imag = run2 + run1.
+// Per layer: the input projection for all T is one MFMA GEMM (idv_pw_gemm for layer 0 straight from the
+// planar encoder output; gemm_rm below for layer 1), then a persistent recurrent kernel walks the T steps.
+// Recurrent kernel: one workgroup = 16 sequences of one run; gates[16 x 4H] = h[16 x H] * W_hh^T on
+// v_mfma_f32_16x16x4_f32; h lives transposed in LDS ([unit][seq], conflict-free A-operand reads),
+// the gate columns are ordered (unit-block, gate, unit) so that i,f,g,o of one (seq, unit) sit in the same
+// lane/register and the cell update is register-local.  For H = 128 the whole W_hh slice of a wave
+// (8 tiles x 32 k-steps = 256 VGPRs) stays in registers for all T steps; other H stream W_hh from L2.
+#include "common.hpp"
+#include "../../include/idccrn_hip.h"
+
+namespace {
+
+struct RecArgs {
+    const float* g;       // gate pre-activations
+    long long g_run_z;    // element stride between z (input part) blocks
+    long long g_run_s;    // element offset between weight sets
+    int ldg;              // row stride of g
+    const float* whh;     // [2 sets][4H/16 tiles][H/4][64]
+    float* hout;          // [4 runs][T*B][H]
+    int H, B, T;
+};
+
+template <bool WREG>
+__global__ __launch_bounds__(256, 1) void lstm_rec_kernel(const RecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int H = WREG ? 128 : a.H;
+    float* hT = sm;                 // [2][H][16]
+    float* cS = sm + 2 * H * 16;    // [H][16]   (generic path only)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int run = blockIdx.y, z = run >> 1, s = run & 1;
+    const int b0 = blockIdx.x * 16;
+    const int col = lane & 15, rq = lane >> 4;          // C/D: col = lane&15, rows rq*4 + r
+    const int KK = H / 4, NUB = H / 16;
+    const float* g = a.g + z * a.g_run_z + s * a.g_run_s;
+    const float* whh = a.whh + (size_t)s * 4 * H * H;
+    float* hout = a.hout + (size_t)run * a.T * a.B * H;
+
+    for (int e = tid; e < 2 * H * 16 + (WREG ? 0 : H * 16); e += 256) sm[e] = 0.f;
+
+    float breg[WREG ? 2 : 1][4][WREG ? 32 : 1];
+    float creg[WREG ? 2 : 1][4];
+    if (WREG) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ub = wave + 4 * u;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) breg[u][gg][kk] = whh[((size_t)(ub * 4 + gg) * KK + kk) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) creg[u][r] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < a.T; ++t) {
+        const float* hc = hT + (t & 1) * H * 16;
+        float* hn = hT + ((t + 1) & 1) * H * 16;
+        const size_t rowbase = (size_t)t * a.B + b0;
+        if (WREG) {
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ub = wave + 4 * u;
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rq * 4 + r;
+                        acc[u][gg][r] = (b0 + row < a.B) ? g[(rowbase + row) * a.ldg + (ub * 4 + gg) * 16 + col] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                const float av = hc[64 * kk + lane];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg)
+                        acc[u][gg] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, breg[u][gg][kk], acc[u][gg], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int unit = (wave + 4 * u) * 16 + col;
+                f32x4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ig = sigmoidf_(acc[u][0][r]), fg = sigmoidf_(acc[u][1][r]);
+                    const float gv = tanhf(acc[u][2][r]), og = sigmoidf_(acc[u][3][r]);
+                    const float cn = fg * creg[u][r] + ig * gv;
+                    creg[u][r] = cn;
+                    hv[r] = og * tanhf(cn);
+                    const int row = rq * 4 + r;
+                    if (b0 + row < a.B) hout[(rowbase + row) * H + unit] = hv[r];
+                }
+                *(f32x4*)&hn[unit * 16 + rq * 4] = hv;
+            }
+        } else {
+            for (int ub = wave; ub < NUB; ub += 4) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rq * 4 + r;
+                        acc[gg][r] = (b0 + row < a.B) ? g[(rowbase + row) * a.ldg + (ub * 4 + gg) * 16 + col] : 0.f;
+                    }
+                const float* wt = whh + (size_t)(ub * 4) * KK * 64 + lane;
+#pragma unroll 4
+                for (int kk = 0; kk < KK; ++kk) {
+                    const float av = hc[64 * kk + lane];
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg)
+                        acc[gg] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wt[((size_t)gg * KK + kk) * 64], acc[gg], 0, 0, 0);
+                }
+                const int unit = ub * 16 + col;
+                f32x4 cv = *(f32x4*)&cS[unit * 16 + rq * 4];
+                f32x4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
+                    const float gv = tanhf(acc[2][r]), og = sigmoidf_(acc[3][r]);
+                    const float cn = fg * cv[r] + ig * gv;
+                    cv[r] = cn;
+                    hv[r] = og * tanhf(cn);
+                    const int row = rq * 4 + r;
+                    if (b0 + row < a.B) hout[(rowbase + row) * H + unit] = hv[r];
+                }
+                *(f32x4*)&cS[unit * 16 + rq * 4] = cv;
+                *(f32x4*)&hn[unit * 16 + rq * 4] = hv;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// G1[run][pos][4H] = X[run][pos][H] * W^T + bias   (layer-1 input projection; X row-major)
+// block: 32 positions x 4H columns of one run; wave w owns column tiles w, w+4, ...
+template <int NCT>   // column tiles (32) per wave = 4H / 128
+__global__ __launch_bounds__(256) void gemm_rm_kernel(const float* __restrict__ X, const float* __restrict__ wfrag,
+                                                      const float* __restrict__ bias, float* __restrict__ G, int H,
+                                                      long long TB, int KS) {
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int run = blockIdx.y, s = run & 1;
+    const long long pos0 = (long long)blockIdx.x * 32;
+    const float* x = X + (size_t)run * TB * H;
+    const int tiles_per_set = (4 * H) / 32;
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int k0 = 0; k0 < H; k0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 32 * 64; e += 256) {
+            const int i = e >> 6, k = e & 63;
+            tile[i][k] = (pos0 + i < TB && k0 + k < H) ? x[(size_t)(pos0 + i) * H + k0 + k] : 0.f;
+        }
+        __syncthreads();
+        const int kmax = min(64, H - k0);
+        for (int kp = 0; kp < kmax; kp += 2) {
+            const float av = tile[l31][kp + half];
+            const int ks = (k0 + kp) >> 1;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int mt = s * tiles_per_set + wave + 4 * c;
+                const float bv = wfrag[((size_t)mt * KS + ks) * 64 + lane];
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[c], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const int colg = (wave + 4 * c) * 32 + l31;                 // column within this set's 4H
+        const float bm = bias[s * 4 * H + colg];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long pos = pos0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (pos < TB) G[((size_t)run * TB + pos) * (4 * H) + colg] = acc[c][r] + bm;
+        }
+    }
+}
+
+// generic (any H multiple of 32): column tiles looped at run time, 4 accumulators at a time
+__global__ __launch_bounds__(256) void gemm_rm_generic_kernel(const float* __restrict__ X, const float* __restrict__ wfrag,
+                                                              const float* __restrict__ bias, float* __restrict__ G, int H,
+                                                              long long TB, int KS) {
+    extern __shared__ float xt[];     // [32][H+1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int run = blockIdx.y, s = run & 1;
+    const long long pos0 = (long long)blockIdx.x * 32;
+    const float* x = X + (size_t)run * TB * H;
+    const int ldx = H + 1;
+    for (int e = tid; e < 32 * H; e += 256) {
+        const int i = e / H, k = e - i * H;
+        xt[i * ldx + k] = (pos0 + i < TB) ? x[(size_t)(pos0 + i) * H + k] : 0.f;
+    }
+    __syncthreads();
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tiles_per_set = (4 * H) / 32;
+    for (int ct = wave; ct < tiles_per_set; ct += 4) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int mt = s * tiles_per_set + ct;
+        for (int kp = 0; kp < H; kp += 2) {
+            const float av = xt[l31 * ldx + kp + half];
+            const float bv = wfrag[((size_t)mt * KS + (kp >> 1)) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        const int colg = ct * 32 + l31;
+        const float bm = bias[s * 4 * H + colg];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long pos = pos0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (pos < TB) G[((size_t)run * TB + pos) * (4 * H) + colg] = acc[r] + bm;
+        }
+    }
+}
+
+// out[0][u][b*Tp+t+1] = h[run0] - h[run3];  out[1][u][...] = h[run2] + h[run1];  guard columns zeroed.
+__global__ __launch_bounds__(256) void lstm_combine_kernel(const float* __restrict__ h, int H, int B, int T, int Tp, int Jp,
+                                                           float* __restrict__ out) {
+    __shared__ float tr[2][32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, u0 = blockIdx.y * 32;
+    const size_t TB = (size_t)T * B;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int i = ty; i < 32; i += 8) {                            // i: t within tile, tx: unit
+        const int t = t0 + i, u = u0 + tx;
+        float re = 0.f, im = 0.f;
+        if (t < T && u < H) {
+            const size_t o = ((size_t)t * B + b) * H + u;
+            re = h[o] - h[3 * TB * H + o];
+            im = h[2 * TB * H + o] + h[1 * TB * H + o];
+        }
+        tr[0][i][tx] = re;
+        tr[1][i][tx] = im;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {                            // i: unit within tile, tx: t
+        const int t = t0 + tx, u = u0 + i;
+        if (t < T && u < H) {
+            const size_t j = (size_t)b * Tp + t + 1;
+            out[(size_t)u * Jp + j] = tr[0][tx][i];
+            out[((size_t)H + u) * Jp + j] = tr[1][tx][i];
+        }
+    }
+    if (blockIdx.x == 0 && tx == 0)
+        for (int i = ty; i < 32; i += 8) {
+            const int u = u0 + i;
+            if (u < H) {
+                out[(size_t)u * Jp + (size_t)b * Tp] = 0.f;
+                out[((size_t)H + u) * Jp + (size_t)b * Tp] = 0.f;
+            }
+        }
+}
+
+__global__ void zero_tail_kernel(float* __restrict__ act, int planes, int B, int T, int Tp, int Jp) {
+    // columns tp in (T, Tp) of every utterance
+    const int tail = Tp - 1 - T;
+    if (tail <= 0) return;
+    const long long n = (long long)planes * B * tail;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % tail);
+        const int b = (int)((idx / tail) % B);
+        const long long pl = idx / ((long long)tail * B);
+        act[(size_t)pl * Jp + (size_t)b * Tp + T + 1 + q] = 0.f;
+    }
+}
+
+int launch_rec(const RecArgs& ra, hipStream_t st) {
+    dim3 grid((ra.B + 15) / 16, 4);
+    if (ra.H == 128) {
+        const size_t smem = (size_t)2 * 128 * 16 * sizeof(float);
+        hipLaunchKernelGGL(lstm_rec_kernel<true>, grid, dim3(256), smem, st, ra);
+    } else {
+        const size_t smem = (size_t)3 * ra.H * 16 * sizeof(float);
+        if (smem > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)lstm_rec_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return IDV_ELAUNCH;
+        hipLaunchKernelGGL(lstm_rec_kernel<false>, grid, dim3(256), smem, st, ra);
+    }
+    return idv_launch_status();
+}
+
+}  // namespace
+
+extern "C" long long idv_clstm_work_floats(int H, int B, int T) { return 24LL * T * B * H; }
+
+extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
+                             const float* wih1, const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp,
+                             float* work, float* out, void* stream) {
+    if (!x || !wih0 || !bih0 || !whh0 || !wih1 || !bih1 || !whh1 || !work || !out) return IDV_EINVAL;
+    if (H <= 0 || (H % 16) || K <= 0 || (K & 1) || B <= 0 || T <= 0 || Tp < T + 1 || Jp < B * Tp) return IDV_EINVAL;
+    if ((size_t)3 * H * 16 * sizeof(float) > 160 * 1024) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const long long TB = (long long)T * B;
+    float* G = work;                       // [2][TB][8H]  then  [4][TB][4H]
+    float* h0 = work + 16 * TB * H;        // [4][TB][H]
+    float* h1 = h0 + 4 * TB * H;
+    int rc;
+    // layer 0 input projection: both weight sets at once (M = 8H), one call per input part z
+    for (int z = 0; z < 2; ++z) {
+        rc = idv_pw_gemm(x + (size_t)z * K * Jp, K, wih0, bih0, nullptr, G + (size_t)z * TB * 8 * H, 8 * H, B, Tp, Jp, T, 1,
+                         8 * H, stream);
+        if (rc) return rc;
+    }
+    RecArgs r0{G, TB * 8 * H, 4LL * H, 8 * H, whh0, h0, H, B, T};
+    if ((rc = launch_rec(r0, st))) return rc;
+    // layer 1 input projection from h0 (row-major), per run
+    const int KS = ((H + 7) / 8) * 4;
+    dim3 ggrid((unsigned)((TB + 31) / 32), 4);
+    if (H == 128) {
+        hipLaunchKernelGGL(gemm_rm_kernel<4>, ggrid, dim3(256), 0, st, h0, wih1, bih1, G, H, TB, KS);
+    } else {
+        const size_t smem = (size_t)32 * (H + 1) * sizeof(float);
+        if (smem > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)gemm_rm_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return IDV_ELAUNCH;
+        hipLaunchKernelGGL(gemm_rm_generic_kernel, ggrid, dim3(256), smem, st, h0, wih1, bih1, G, H, TB, KS);
+    }
+    if ((rc = idv_launch_status())) return rc;
+    // G1 is [run][TB][4H] with run = 2z + s
+    RecArgs r1{G, 2 * TB * 4 * H, TB * 4 * H, 4 * H, whh1, h1, H, B, T};
+    if ((rc = launch_rec(r1, st))) return rc;
+    hipLaunchKernelGGL(lstm_combine_kernel, dim3((T + 31) / 32, (H + 31) / 32, B), dim3(256), 0, st, h1, H, B, T, Tp, Jp, out);
+    const long long ntail = 2LL * H * B * (Tp - 1 - T);
+    if (ntail > 0)
+        hipLaunchKernelGGL(zero_tail_kernel, dim3((unsigned)((ntail + 255) / 256 > 4096 ? 4096 : (ntail + 255) / 256)), dim3(256), 0,
+                           st, out, 2 * H, B, T, Tp, Jp);
+    return idv_launch_status();
+}

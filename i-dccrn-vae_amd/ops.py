@@ -1,0 +1,304 @@
+"""Thin host wrappers over the C ABI: planar-J activation buffers and one python function per
+idv_* operator.  PyTorch is used for device memory and streams only; all arithmetic of the hot
+path happens inside libidccrn_hip.so."""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from ._lib import call, p, i, f, d, ll, stream_ptr
+
+SLACK = 256
+
+
+class Planar:
+    """A planar-J activation  act[2][C][F][Jp]  (see include/idccrn_hip.h).
+
+    ``T`` is the number of valid frames (t_valid); ``Tp`` = T_stft + 1 columns per utterance.
+    ``tensor5()`` exposes it with the reference's shape [B, C, F, T, 2] as a strided view.
+    """
+
+    __slots__ = ("buf", "C", "F", "B", "T", "Tp", "Jp")
+
+    def __init__(self, buf, C, F, B, T, Tp, Jp):
+        self.buf, self.C, self.F, self.B, self.T, self.Tp, self.Jp = buf, C, F, B, T, Tp, Jp
+
+    @staticmethod
+    def jp_for(B: int, Tp: int) -> int:
+        return (B * Tp + 3) // 4 * 4
+
+    @classmethod
+    def empty(cls, C, F, B, T, Tp, device, zero=False):
+        Jp = cls.jp_for(B, Tp)
+        n = 2 * C * F * Jp + 2 * SLACK
+        buf = (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=device)
+        return cls(buf, C, F, B, T, Tp, Jp)
+
+    @property
+    def data(self) -> torch.Tensor:
+        return self.buf[SLACK:SLACK + 2 * self.C * self.F * self.Jp]
+
+    def ptr(self, plane_offset: int = 0):
+        """Device pointer to plane `plane_offset` (planes are F*Jp floats... of size Jp per row)."""
+        return L._P(self.buf.data_ptr() + 4 * (SLACK + plane_offset * self.F * self.Jp))
+
+    def planes(self) -> torch.Tensor:
+        """[2, C, F, B, Tp] view (requires Jp == B*Tp padding handled by as_strided)."""
+        return torch.as_strided(self.buf, (2, self.C, self.F, self.B, self.Tp),
+                                (self.C * self.F * self.Jp, self.F * self.Jp, self.Jp, self.Tp, 1), SLACK)
+
+    def tensor5(self) -> torch.Tensor:
+        """Reference-shaped view [B, C, F, T, 2]."""
+        return self.planes()[..., 1:1 + self.T].permute(3, 1, 2, 4, 0)
+
+    def tensor4(self) -> torch.Tensor:
+        """[B, F, T, 2] view for C == 1 (or [B, C*F...] callers reshape themselves)."""
+        return self.tensor5()[:, 0]
+
+    def channel_slice(self, c0: int, c1: int) -> torch.Tensor:
+        """[B, T, c1-c0, 2] view for F == 1 activations (LSTM outputs / latents)."""
+        assert self.F == 1
+        return self.planes()[:, c0:c1, 0, :, 1:1 + self.T].permute(2, 3, 1, 0)
+
+    @classmethod
+    def from_tensor5(cls, x: torch.Tensor, Tp: Optional[int] = None):
+        """Copy a reference-layout tensor [B, C, F, T, 2] into a fresh planar buffer."""
+        B, C, F, T, _ = x.shape
+        Tp = Tp or T + 1
+        out = cls.empty(C, F, B, T, Tp, x.device, zero=True)
+        out.tensor5().copy_(x)
+        return out
+
+
+def _dev_scratch(n: int, device, dtype=torch.float32, zero=False):
+    return (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=device)
+
+
+# ----------------------------------------------------------------------------- packing
+def mtiles_alloc(M: int) -> int:
+    return (M + 127) // 128 * 4
+
+
+def cbn_fold(moments, g_rr, g_ri, g_ii, b_r, b_i):
+    """moments: [5, C] tensor (mean_r, mean_i, Vrr, Vri, Vii) -> fold [C, 6]."""
+    C = g_rr.numel()
+    fold = torch.empty(C, 6, dtype=torch.float32, device=g_rr.device)
+    call("idv_cbn_fold", p(moments), p(g_rr), p(g_ri), p(g_ii), p(b_r), p(b_i), i(C), p(fold), stream_ptr())
+    return fold
+
+
+def pack_cconv(w_re, w_im, b_re, b_im, fold, cin_used: Optional[int] = None, transposed=False):
+    """-> (wfrag, bias) for idv_cconv2d_fwd."""
+    if transposed:
+        cin_total, cout = w_re.shape[0], w_re.shape[1]
+    else:
+        cout, cin_total = w_re.shape[0], w_re.shape[1]
+    cin_used = cin_total if cin_used is None else cin_used
+    cck = L.lib().idv_cconv_cck(cin_used)
+    ccp = (2 * cin_used + cck - 1) // cck * cck
+    mt = mtiles_alloc(2 * cout)
+    wfrag = torch.empty(mt * ccp * 5 * 64, dtype=torch.float32, device=w_re.device)
+    bias = torch.empty(mt * 32, dtype=torch.float32, device=w_re.device)
+    call("idv_pack_cconv", p(w_re.contiguous()), p(w_im.contiguous()), p(b_re.contiguous()), p(b_im.contiguous()),
+         p(fold), i(cout), i(cin_total), i(cin_used), i(1 if transposed else 0), p(wfrag), p(bias), stream_ptr())
+    return wfrag, bias
+
+
+def pack_pw(w, bias):
+    M, K = w.shape
+    mt = mtiles_alloc(M)
+    ks = (K + 7) // 8 * 4
+    wfrag = torch.empty(mt * ks * 64, dtype=torch.float32, device=w.device)
+    bout = torch.empty(mt * 32, dtype=torch.float32, device=w.device)
+    call("idv_pack_pw", p(w.contiguous()), p(None if bias is None else bias.contiguous()), i(M), i(K), p(wfrag),
+         p(bout), stream_ptr())
+    return wfrag, bout
+
+
+# ----------------------------------------------------------------------------- forward ops
+def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True, slope=None, skip: Optional[Planar] = None,
+            skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None) -> Planar:
+    """(causal_)ComplexConv2d / (causal_)ComplexConvTranspose2d forward on planar activations."""
+    Fout = 2 * x.F - 1 if transposed else (x.F - 1) // 2 + 1
+    if causal:
+        t_out = x.T
+    else:
+        t_out = x.T + 1 if transposed else x.T - 1
+    tshift = -1 if (causal or transposed) else 0
+    if out is None:
+        out = Planar.empty(cout, Fout, x.B, t_out, x.Tp, x.buf.device)
+    c1 = skip.C if skip is not None else 0
+    call("idv_cconv2d_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
+         i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag), p(bias), p(slope), out.ptr(), p(stats),
+         i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+    return out
+
+
+def pw_gemm(x_ptr, K: int, wfrag, bias, M: int, B: int, Tp: int, Jp: int, t_valid: int, out_ptr, *, slope=None,
+            swap=False, ldo=0):
+    call("idv_pw_gemm", x_ptr, i(K), p(wfrag), p(bias), p(slope), out_ptr, i(M), i(B), i(Tp), i(Jp), i(t_valid),
+         i(1 if swap else 0), i(ldo), stream_ptr())
+
+
+def pack_lstm(sd_get, H: int, K: int, layer: int, device):
+    """sd_get(name) -> tensor for names like 'lstm_re.weight_ih_l0'.  Returns (wih, bih, whh)."""
+    g = lambda n: sd_get(n).contiguous()
+    l = layer
+    M = 8 * H
+    mt = mtiles_alloc(M)
+    ks = (K + 7) // 8 * 4
+    wih = torch.empty(mt * ks * 64, dtype=torch.float32, device=device)
+    bih = torch.empty(mt * 32, dtype=torch.float32, device=device)
+    call("idv_pack_lstm_ih", p(g(f"lstm_re.weight_ih_l{l}")), p(g(f"lstm_re.bias_ih_l{l}")), p(g(f"lstm_re.bias_hh_l{l}")),
+         p(g(f"lstm_im.weight_ih_l{l}")), p(g(f"lstm_im.bias_ih_l{l}")), p(g(f"lstm_im.bias_hh_l{l}")), i(H), i(K),
+         p(wih), p(bih), stream_ptr())
+    whh = torch.empty(2 * 4 * H * H, dtype=torch.float32, device=device)
+    call("idv_pack_lstm_hh", p(g(f"lstm_re.weight_hh_l{l}")), p(g(f"lstm_im.weight_hh_l{l}")), i(H), p(whh), stream_ptr())
+    return wih, bih, whh
+
+
+def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
+    """ComplexLSTM forward: x planar with C*F = K feature planes per part -> planar [2][H][Jp] (F = 1)."""
+    K = x.C * x.F
+    out = Planar.empty(H, 1, x.B, x.T, x.Tp, x.buf.device)
+    nwork = L.lib().idv_clstm_work_floats(i(H), i(x.B), i(x.T))
+    work = torch.empty(nwork, dtype=torch.float32, device=x.buf.device)
+    call("idv_clstm_fwd", x.ptr(), i(K), p(packed0[0]), p(packed0[1]), p(packed0[2]), p(packed1[0]), p(packed1[1]),
+         p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), stream_ptr())
+    return out
+
+
+def cdense(x: Planar, packed_r, packed_i, M: int, C_out: int, F_out: int) -> Planar:
+    """ComplexDense on a planar [2][K][Jp] activation -> planar [2][C_out][F_out][Jp] (M = C_out*F_out)."""
+    K = x.C * x.F
+    out = Planar.empty(C_out, F_out, x.B, x.T, x.Tp, x.buf.device)
+    for ri, (wf, bf) in enumerate((packed_r, packed_i)):
+        pw_gemm(x.ptr(ri * x.C), K, wf, bf, M, x.B, x.Tp, x.Jp, x.T, out.ptr(ri * C_out))
+    return out
+
+
+class DftPlan:
+    """Windowed DFT / inverse DFT matrices for one (n_fft, win, hop, T), packed for idv_pw_gemm."""
+
+    def __init__(self, n_fft, win, hop, T, device):
+        self.n_fft, self.win, self.hop, self.T = n_fft, win, hop, T
+        self.F = n_fft // 2 + 1
+        F = self.F
+        w_fwd = torch.empty(2 * F, win, dtype=torch.float32, device=device)
+        w_inv = torch.empty(win, 2 * F, dtype=torch.float32, device=device)
+        self.env_inv = torch.empty(n_fft + hop * (T - 1), dtype=torch.float32, device=device)
+        call("idv_make_dft", i(n_fft), i(win), i(hop), i(T), p(w_fwd), p(w_inv), p(self.env_inv), stream_ptr())
+        self.fwd = pack_pw(w_fwd, None)
+        self.inv = pack_pw(w_inv, None)
+
+
+def stft(x: torch.Tensor, plan: DftPlan, Tp: Optional[int] = None) -> Planar:
+    """STFT.forward: x [B, L] -> planar [2][1][F][Jp]."""
+    B, Lx = x.shape
+    T = 1 + Lx // plan.hop
+    assert T == plan.T, "DftPlan built for another length"
+    Tp = Tp or T + 1
+    x = x.contiguous()
+    fr = Planar.empty(1, plan.win // 2, B, T, Tp, x.device)      # [win][Jp] scratch (2*C*F = win planes)
+    assert plan.win % 2 == 0
+    call("idv_stft_frames", p(x), i(B), i(Lx), i(plan.n_fft), i(plan.win), i(plan.hop), i(T), fr.ptr(), i(Tp), i(fr.Jp),
+         stream_ptr())
+    out = Planar.empty(1, plan.F, B, T, Tp, x.device)
+    pw_gemm(fr.ptr(), plan.win, plan.fwd[0], plan.fwd[1], 2 * plan.F, B, Tp, fr.Jp, T, out.ptr())
+    return out
+
+
+def istft(spec: Planar, plan: DftPlan) -> torch.Tensor:
+    """ISTFT.forward: planar [2][1][F][Jp] -> y [B, hop*(T-1)]."""
+    B, T = spec.B, spec.T
+    fr = Planar.empty(1, plan.win // 2, B, T, spec.Tp, spec.buf.device)
+    pw_gemm(spec.ptr(), 2 * plan.F, plan.inv[0], plan.inv[1], plan.win, B, spec.Tp, spec.Jp, T, fr.ptr())
+    y = torch.empty(B, plan.hop * (T - 1), dtype=torch.float32, device=spec.buf.device)
+    call("idv_istft_ola", fr.ptr(), p(plan.env_inv), i(B), i(plan.n_fft), i(plan.win), i(plan.hop), i(T), i(spec.Tp),
+         i(fr.Jp), p(y), stream_ptr())
+    return y
+
+
+def mask_apply(mask: Planar, X: Planar, x_div: int = 1):
+    """-> (pred planar, pred complex64 [B, F, T])."""
+    B, F, T = mask.B, mask.F, mask.T
+    pred = Planar.empty(1, F, B, T, mask.Tp, mask.buf.device)
+    pc = torch.empty(B, F, T, 2, dtype=torch.float32, device=mask.buf.device)
+    call("idv_mask_apply", mask.ptr(), X.ptr(), i(x_div), i(X.Jp), pred.ptr(), p(pc), i(F), i(B), i(T), i(mask.Tp),
+         i(mask.Jp), stream_ptr())
+    return pred, torch.view_as_complex(pc)
+
+
+def planar_to_complex(act: Planar) -> torch.Tensor:
+    pc = torch.empty(act.B, act.F, act.T, 2, dtype=torch.float32, device=act.buf.device)
+    call("idv_planar_to_complex", act.ptr(), p(pc), i(act.F), i(act.B), i(act.T), i(act.Tp), i(act.Jp), stream_ptr())
+    return torch.view_as_complex(pc)
+
+
+def cbn_train(act: Planar, stats: torch.Tensor, bn, slope, first_call: bool, momentum: float = 0.9):
+    """Finish a train-mode conv block: stats (filled by cconv2d(stats=...)) -> batch moments, running
+    buffers (in place, on the module's own buffers), then y = PReLU(Z x + s) in place on `act`."""
+    C = act.C
+    dev = act.buf.device
+    moments = torch.empty(5, C, dtype=torch.float32, device=dev)
+    fold = torch.empty(C, 6, dtype=torch.float32, device=dev)
+    count = float(act.B) * act.F * act.T
+    call("idv_cbn_finalize", p(stats), d(count), p(bn.gamma_rr), p(bn.gamma_ri), p(bn.gamma_ii), p(bn.beta_r), p(bn.beta_i),
+         i(C), i(1 if first_call else 0), f(momentum), p(bn.running_mean_real), p(bn.running_mean_imag), p(bn.Vrr), p(bn.Vri),
+         p(bn.Vii), p(moments), p(fold), stream_ptr())
+    call("idv_cbn_apply_prelu", act.ptr(), p(fold), p(slope), i(C), i(act.F), i(act.B), i(act.Tp), i(act.Jp), i(act.T),
+         stream_ptr())
+    return moments
+
+
+def reparam(lat: Planar, off, zdim: int, eps_r, eps_i, ns: int) -> Planar:
+    """reparameterization on a planar latent; off = (miu, log_sigma, delta) channel offsets."""
+    B, T = lat.B, lat.T
+    z = Planar.empty(zdim, 1, B * ns, T, lat.Tp, lat.buf.device)
+    call("idv_reparam", lat.ptr(), i(lat.C), i(off[0]), i(off[1]), i(off[2]), i(zdim), p(eps_r.contiguous()),
+         p(eps_i.contiguous()), i(ns), i(B), i(T), i(lat.Tp), i(lat.Jp), z.ptr(), i(z.Jp), stream_ptr())
+    return z
+
+
+# ----------------------------------------------------------------------------- losses
+def sisnr(source: torch.Tensor, est: torch.Tensor, src_div: int = 1) -> torch.Tensor:
+    B, Ln = est.shape
+    assert source.stride(-1) == 1 and est.stride(-1) == 1
+    work = torch.empty(3 * B, dtype=torch.float64, device=est.device)
+    out = torch.empty(1, dtype=torch.float32, device=est.device)
+    call("idv_sisnr", p(source), i(source.stride(0)), i(src_div), p(est), i(est.stride(0)), i(B), i(Ln), p(work), p(out),
+         stream_ptr())
+    return out[0]
+
+
+def recon_loss(pred_c: torch.Tensor, ori: torch.Tensor, ori_div: int = 1):
+    """pred_c: complex64 [B,F,T] (contiguous); ori: [B/ori_div, F, T, 2] real, any strides -> (cpx, mag)."""
+    pr = torch.view_as_real(pred_c)
+    assert pr.is_contiguous()
+    B, F, T, _ = pr.shape
+    work = torch.empty(3, dtype=torch.float64, device=pr.device)
+    out = torch.empty(2, dtype=torch.float32, device=pr.device)
+    sb, sf, st, sr = ori.stride()
+    call("idv_recon_loss", p(pr), p(ori), ll(sb), ll(sf), ll(st), ll(sr), i(ori_div), i(B), i(F), i(T), p(work), p(out),
+         stream_ptr())
+    return out[0], out[1]
+
+
+def ckl(q1: Planar, off1, q2: Optional[Planar], off2, zdim: int, eps: float) -> torch.Tensor:
+    work = torch.empty(3, dtype=torch.float64, device=q1.buf.device)
+    out = torch.empty(1, dtype=torch.float32, device=q1.buf.device)
+    o2 = off2 if q2 is not None else (0, 0, 0)
+    call("idv_ckl", q1.ptr(), i(q1.C), i(q1.Jp), i(off1[0]), i(off1[1]), i(off1[2]),
+         q2.ptr() if q2 is not None else p(None), i(q2.C if q2 is not None else 0), i(q2.Jp if q2 is not None else 0),
+         i(o2[0]), i(o2[1]), i(o2[2]), i(zdim), f(eps), i(q1.B), i(q1.T), i(q1.Tp), p(work), p(out), stream_ptr())
+    return out[0]
+
+
+def miu_dist(q1: Planar, off1: int, q2: Planar, off2: int, zdim: int) -> torch.Tensor:
+    work = torch.empty(3 * 2 * zdim, dtype=torch.float64, device=q1.buf.device)
+    out = torch.empty(1, dtype=torch.float32, device=q1.buf.device)
+    call("idv_miu_dist", q1.ptr(), i(q1.C), i(q1.Jp), i(off1), q2.ptr(), i(q2.C), i(q2.Jp), i(off2), i(zdim), i(q1.B), i(q1.T),
+         i(q1.Tp), p(work), p(out), stream_ptr())
+    return out[0]

@@ -1,0 +1,152 @@
+/* libidccrn_hip.so -- C ABI of the MI355X (gfx950) I-DCCRN-VAE enhancement hot path.
+ *
+ * The reference (iris1997jiatong/I-DCCRN-VAE) is pure PyTorch and has no FFI of its own; each entry
+ * point below replaces the stock torch operator(s) behind one reference function (file:line cited
+ * per entry, paths relative to the reference root).  Conventions:
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch.cuda memory) unless it says "host";
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it, never allocate,
+ *     never synchronise, keep no global state (re-entrant across streams);
+ *   - return value: 0 ok, -1 invalid argument, -2 launch failure; nothing throws;
+ *   - activations use the planar-J layout  act[ri][C][F][Jp]  (fp32):
+ *       column j = b*Tp + tp, Tp = T+1, tp = t+1, tp==0 and tp>t_valid are zero guard columns,
+ *       Jp >= B*Tp is the row stride; buffers need IDV_SLACK floats of slack in front and behind.
+ *     A reference tensor x[B,C,F,T,2] is act.view(2,C,F,B,Tp)[..., 1:].permute(3,1,2,4,0).
+ */
+#ifndef IDCCRN_HIP_H
+#define IDCCRN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDV_ABI_VERSION 1
+#define IDV_SLACK_FLOATS 256
+
+int idv_abi_version(void);
+
+/* ---- weight preparation (device -> device, run once per parameter update) ------------------ */
+
+/* K-chunk (in planar channels) the contraction kernel uses for `cin_used` complex input channels;
+ * wfrag for a complex conv holds  roundup(2*Cout,128)/32 * roundup(2*cin_used, cck)*5 * 64 floats. */
+int idv_cconv_cck(int cin_used);
+
+/* ComplexBatchNormal statistics -> affine: model/complex_progress.py:168-209 (cbn).
+ * moments: [5][C] = mean_r, mean_i, Vrr, Vri, Vii (Vrr/Vii already carry +1e-5, as the reference's
+ * running buffers do).  fold[C][6] = Zrr,Zri,Zir,Zii, sr, si with  y = Z*x + s. */
+int idv_cbn_fold(const float* moments, const float* gamma_rr, const float* gamma_ri, const float* gamma_ii,
+                 const float* beta_r, const float* beta_i, int C, float* fold, void* stream);
+
+/* Pack ComplexConv2d / causal_complex_conv2d weights (complex_progress.py:8-36; w_*: [Cout,Cin,5,2])
+ * or (Causal)ComplexConvTranspose2d weights (:222-279; w_*: [Cin,Cout,5,2], transposed=1) into the
+ * MFMA fragment order of the block matrix [[Wr,-Wi],[Wi,Wr]]; biases become (b_re-b_im, b_re+b_im)
+ * (:16-18,:32-34).  fold (or NULL) is applied on the output side (eval-mode BN folded into the conv). */
+int idv_pack_cconv(const float* w_re, const float* w_im, const float* b_re, const float* b_im, const float* fold,
+                   int Cout, int Cin_total, int Cin_used, int transposed, float* wfrag, float* bias_out, void* stream);
+
+/* Pack a row-major real matrix w[M][K] (+ bias[M] or NULL) for idv_pw_gemm;
+ * wfrag holds roundup(M,128)/32 * roundup(K,8)/2 * 64 floats, bias_out roundup(M,128). */
+int idv_pack_pw(const float* w, const float* bias, int M, int K, float* wfrag, float* bias_out, void* stream);
+
+/* nn.LSTM input weights of ComplexLSTM (complex_progress.py:45-48): rows of the packed matrix are
+ * [lstm_re gates | lstm_im gates], gate columns re-ordered for the recurrent kernel, bias = b_ih + b_hh.
+ * w_ih_*: [4H][K].  Same sizes as idv_pack_pw with M = 8H. */
+int idv_pack_lstm_ih(const float* w_ih_re, const float* b_ih_re, const float* b_hh_re, const float* w_ih_im,
+                     const float* b_ih_im, const float* b_hh_im, int H, int K, float* wfrag, float* bias_out,
+                     void* stream);
+/* Recurrent weights w_hh_*: [4H][H] -> fragment order of the recurrent kernel, 2*4H*H floats. */
+int idv_pack_lstm_hh(const float* w_hh_re, const float* w_hh_im, int H, float* whh_frag, void* stream);
+
+/* Windowed DFT / inverse-DFT matrices of torch.stft / torch.istft as used by STFT.forward /
+ * ISTFT.forward (model/pvae_module.py:21-27, :38-42): hann(win) centred in n_fft, onesided.
+ * w_fwd: [2F][win] row-major, w_inv: [win][2F] row-major, F = n_fft/2+1; env_inv: [n_fft + hop*(T-1)]
+ * = 1 / overlap-added squared window (0 where the envelope is 0). */
+int idv_make_dft(int n_fft, int win, int hop, int T, float* w_fwd, float* w_inv, float* env_inv, void* stream);
+
+/* ---- forward operators ---------------------------------------------------------------------- */
+
+/* ComplexConv2d.forward / causal_complex_conv2d.forward (complex_progress.py:16-22, :32-36) and
+ * (causal_)ComplexConvTranspose2d.forward (:244-250, :275-279), kernel (5,2), stride (2,1), freq
+ * padding 2; fused with torch.cat([p, skip], 1) of standard_DCCRN.forward (pvae_module.py:195;
+ * x1 = skip, x1_div = num_samples for the repeated skips of pvae_module.py:2563-2567), with the
+ * folded eval BatchNorm and PReLU (pvae_module.py:64-68, :88-93) when prelu_slope != NULL, and with
+ * the train-mode moment sums (complex_progress.py:132-143) when stats != NULL (stats: [Cout][5]
+ * doubles, zeroed by the caller: sum r, i, r*r, i*i, r*i over kept positions).
+ * tshift: -1 causal conv / any transposed conv, 0 non-causal conv.  t_valid_out: frames kept. */
+int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const float* wfrag,
+                    const float* bias, const float* prelu_slope, float* out, double* stats, int transposed,
+                    int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
+
+/* out[m][j] = bias[m] + sum_k w[m][k] x[k][j] over K planes of stride Jp: ComplexDense.forward
+ * (complex_progress.py:83-89, one call per real/imag linear), the LSTM input projections, and the
+ * DFT / inverse DFT.  swap=1 writes out[((tp-1)*B + b)*ldo + m] instead of planar rows. */
+int idv_pw_gemm(const float* x, int K, const float* wfrag, const float* bias, const float* prelu_slope, float* out,
+                int M, int B, int Tp, int Jp, int t_valid, int swap, int ldo, void* stream);
+
+/* Train-mode ComplexBatchNormal (complex_progress.py:131-160): sums -> moments[5][C] (mean_r, mean_i,
+ * Vrr+eps, Vri, Vii+eps), running buffers updated in place (first call copies, later 0.9/0.1 blend),
+ * fold[C][6] for idv_cbn_apply_prelu. count = B*F*T. */
+int idv_cbn_finalize(const double* stats, double count, const float* gamma_rr, const float* gamma_ri,
+                     const float* gamma_ii, const float* beta_r, const float* beta_i, int C, int first_call,
+                     float momentum, float* running_mean_r, float* running_mean_i, float* Vrr, float* Vri,
+                     float* Vii, float* moments, float* fold, void* stream);
+/* y = PReLU(Z*x + s) in place on a planar activation, guard columns stay zero. */
+int idv_cbn_apply_prelu(float* act, const float* fold, const float* prelu_slope, int C, int F, int B, int Tp, int Jp,
+                        int t_valid, void* stream);
+
+/* STFT.forward (pvae_module.py:21-27): x[B][L] -> frames[win][Jp] (reflect-padded, centred frames);
+ * the DFT itself is idv_pw_gemm with the idv_make_dft matrix. */
+int idv_stft_frames(const float* x, int B, int L, int n_fft, int win, int hop, int T, float* frames, int Tp, int Jp,
+                    void* stream);
+/* ISTFT.forward (pvae_module.py:38-42) tail: overlap-add of windowed inverse-DFT frames
+ * frames[win][Jp] / envelope, trimmed to y[B][hop*(T-1)]. */
+int idv_istft_ola(const float* frames, const float* env_inv, int B, int n_fft, int win, int hop, int T, int Tp,
+                  int Jp, float* y, void* stream);
+
+/* Mask branch of DCCRN_.forward (pvae_module.py:224-234) / decoder_twophase (:2594-2608):
+ * predict = |X| tanh|M| exp(j(angle X + angle M)).  mask, X: planar [2][F][Jp] (X utterance b/x_div);
+ * writes planar `pred` and the interleaved complex64 API tensor pred_c[B][F][T][2]. */
+int idv_mask_apply(const float* mask, const float* X, int x_div, int JpX, float* pred, float* pred_c, int F, int B,
+                   int T, int Tp, int Jp, void* stream);
+/* planar [2][F][Jp] -> interleaved [B][F][T][2] (recon_type 'real_imag', pvae_module.py:245-253). */
+int idv_planar_to_complex(const float* act, float* out_c, int F, int B, int T, int Tp, int Jp, void* stream);
+
+/* ComplexLSTM.forward (complex_progress.py:50-74): four 2-layer LSTM passes, real = rr - ii,
+ * imag = ir + ri.  x: planar [2][K][Jp]; out: planar [2][H][Jp].  wihN / bihN: idv_pack_lstm_ih of layer
+ * N, whhN: idv_pack_lstm_hh of layer N.  work: idv_clstm_work_floats(H, B, T) floats. */
+long long idv_clstm_work_floats(int H, int B, int T);
+int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0, const float* wih1,
+                  const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp, float* work, float* out,
+                  void* stream);
+
+/* reparameterization (pvae_module.py:1832-1886) with the two randn draws supplied by the caller.
+ * lat: planar LSTM output [2][Hl][Jp]; miu/log_sigma/delta are channel offsets off_miu/off_ls/off_dl
+ * (zdim channels each).  eps_r/eps_i: [B][ns][T][zdim].  z: planar [2][zdim][Jpz], columns (b*ns+s)*Tp+tp. */
+int idv_reparam(const float* lat, int Hl, int off_miu, int off_ls, int off_dl, int zdim, const float* eps_r,
+                const float* eps_i, int ns, int B, int T, int Tp, int Jp, float* z, int Jpz, void* stream);
+
+/* ---- losses ---------------------------------------------------------------------------------- */
+
+/* si_snr (model/sisnr_loss.py:7-19): three dot products per utterance; out[0] = -mean_b(snr).
+ * src_div: source row = b / src_div (repeat over num_samples).  work: 3*B doubles (zeroed here). */
+int idv_sisnr(const float* source, int src_ld, int src_div, const float* est, int est_ld, int B, int L, double* work,
+              float* out, void* stream);
+/* multiple_recon_loss terms (model/nsvae_loss.py:775-797): out[0] = loss_cpx, out[1] = loss_mag
+ * (the original magnitude uses the real part twice, nsvae_loss.py:783).  pred_c: interleaved
+ * [B][F][T][2]; ori: element (b,f,t,ri) at ori[(b/ori_div)*sb + f*sf + t*st + ri*sr]. */
+int idv_recon_loss(const float* pred_c, const float* ori, long long sb, long long sf, long long st, long long sr,
+                   int ori_div, int B, int F, int T, double* work, float* out, void* stream);
+/* Closed-form complex-Gaussian KL, mean over (b,t): cal_kl_arbi_prior
+ * (model/pretrain_pvaes_loss.py:225-281, eps 1e-9) / cal_kl (model/nsvae_loss.py:275-328, eps 1e-10).
+ * q1, q2: planar latents [2][Hn][Jpn] with channel offsets on_miu / on_ls / on_dl; q2 == NULL is the
+ * standard prior (0, 0, 0).  work: 3 doubles.  out[0] = mean KL. */
+int idv_ckl(const float* q1, int H1, int Jp1, int o1_miu, int o1_ls, int o1_dl, const float* q2, int H2, int Jp2,
+            int o2_miu, int o2_ls, int o2_dl, int zdim, float eps, int B, int T, int Tp, double* work, float* out,
+            void* stream);
+/* miu_dis_loss term (model/nsvae_loss.py:349-360): sqrt(sum_{h,ri} mean_{b,t} (miu1 - miu2)^2). */
+int idv_miu_dist(const float* q1, int H1, int Jp1, int off1, const float* q2, int H2, int Jp2, int off2, int zdim,
+                 int B, int T, int Tp, double* work, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
