@@ -148,6 +148,31 @@ __global__ void cbn_finalize_kernel(const double* __restrict__ stats, double cou
     z[5] = b_i[c] - (Zir * mu_r + Zii * mu_i);
 }
 
+// five moments of one channel of a planar activation (stand-alone ComplexBatchNormal.forward);
+// grid = (chunks, C*F rows); double atomics into stats[c][5]
+__global__ __launch_bounds__(256) void cbn_stats_kernel(const float* __restrict__ act, int C, int F, int B, int Tp, int Jp,
+                                                        int t_valid, double* __restrict__ stats) {
+    const int row = blockIdx.y, c = row / F;
+    const float* pr = act + (size_t)row * Jp;
+    const float* pi = act + ((size_t)C * F + row) * Jp;
+    const int J = B * Tp;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < J; j += gridDim.x * blockDim.x) {
+        const int tp = j % Tp;
+        if (tp < 1 || tp > t_valid) continue;
+        const double r = pr[j], im = pi[j];
+        s[0] += r; s[1] += im; s[2] += r * r; s[3] += im * im; s[4] += r * im;
+    }
+    __shared__ double sh[5][4];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const double v = wave_sum_d(s[q]);
+        if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) atomicAdd(&stats[(size_t)c * 5 + threadIdx.x], sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
 // in place: (r, i) <- PReLU(Z (r, i) + s) on kept columns; grid = (column tiles, C*F rows)
 __global__ void cbn_apply_prelu_kernel(float* __restrict__ act, const float* __restrict__ fold,
                                        const float* __restrict__ slope_p, int C, int F, int B, int Tp, int Jp, int t_valid) {
@@ -261,6 +286,15 @@ extern "C" int idv_cbn_finalize(const double* stats, double count, const float* 
     hipLaunchKernelGGL(cbn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, count, gamma_rr,
                        gamma_ri, gamma_ii, beta_r, beta_i, C, first_call, momentum, running_mean_r, running_mean_i, Vrr, Vri,
                        Vii, moments, fold);
+    return idv_launch_status();
+}
+
+extern "C" int idv_cbn_stats(const float* act, int C, int F, int B, int Tp, int Jp, int t_valid, double* stats, void* stream) {
+    if (!act || !stats || C <= 0 || F <= 0 || B <= 0) return IDV_EINVAL;
+    const int J = B * Tp;
+    int gx = (J + 255) / 256;
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(cbn_stats_kernel, dim3(gx, C * F), dim3(256), 0, (hipStream_t)stream, act, C, F, B, Tp, Jp, t_valid, stats);
     return idv_launch_status();
 }
 

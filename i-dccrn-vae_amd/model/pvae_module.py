@@ -1,0 +1,429 @@
+"""Model assembly with the reference's class names, constructor signatures, forward() signatures,
+return tuples and state_dict keys (reference: model/pvae_module.py), running on the HIP kernels.
+
+Classes: STFT, ISTFT, Encoder, Decoder, standard_DCCRN, DCCRN_ (supervised DCCRN-CL),
+pvae_dccrn_encoder_skip_prepare / pvae_dccrn_decoder_skip_prepare (CVAE / NVAE pre-training),
+nsvae_pvae_dccrn_encoder_twophase / nsvae_pvae_dccrn_decoder_twophase (NSVAE and decoder fine-tune).
+The reference's other encoder/decoder variants are ablation copies of these.
+
+A batch stays in the planar-J device layout from STFT to ISTFT; tensors handed back to the caller
+(skiper, stft_x, z, miu, ...) are strided views with the reference's shapes, and carry their planar
+buffer so that passing them into the decoder costs no copy.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import Planar
+from .complex_progress import (ComplexBatchNormal, ComplexConv2d, ComplexConvTranspose2d, ComplexDense, ComplexLSTM,
+                               causal_complex_conv2d, causal_ComplexConvTranspose2d, planar_of, tag5)
+
+_PLANS = {}
+
+
+def dft_plan(n_fft, win, hop, T, device) -> ops.DftPlan:
+    key = (n_fft, win, hop, T, str(device))
+    if key not in _PLANS:
+        _PLANS[key] = ops.DftPlan(n_fft, win, hop, T, device)
+    return _PLANS[key]
+
+
+def _need_cuda(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("i-dccrn-vae_amd runs on the MI355X only: pass CUDA (ROCm) tensors; there is no CPU path")
+
+
+class STFT(nn.Module):
+    """reference: model/pvae_module.py:12-27 (torch.stft, hann(win), center/reflect) -> [B, F, T, 2]"""
+
+    def __init__(self, n_fft, hop_length, win_length, device):
+        super().__init__()
+        self.n_fft, self.hop_length, self.win_length = n_fft, hop_length, win_length
+
+    def planar(self, signal: torch.Tensor) -> Planar:
+        _need_cuda(signal)
+        T = 1 + signal.shape[1] // self.hop_length
+        return ops.stft(signal.float(), dft_plan(self.n_fft, self.win_length, self.hop_length, T, signal.device))
+
+    def forward(self, signal):
+        pl = self.planar(signal)
+        x = pl.tensor4()
+        x._idv = pl
+        return x
+
+
+class ISTFT(nn.Module):
+    """reference: model/pvae_module.py:30-42 (torch.istft) : complex [B, F, T] -> [B, hop*(T-1)]"""
+
+    def __init__(self, n_fft, hop_length, win_length, device):
+        super().__init__()
+        self.n_fft, self.hop_length, self.win_length = n_fft, hop_length, win_length
+
+    def planar(self, spec: Planar) -> torch.Tensor:
+        return ops.istft(spec, dft_plan(self.n_fft, self.win_length, self.hop_length, spec.T, spec.buf.device))
+
+    def forward(self, x):
+        pl = getattr(x, "_idv", None)
+        if pl is None:
+            _need_cuda(x)
+            pl = Planar.from_tensor5(torch.view_as_real(x).unsqueeze(1).float())
+        return self.planar(pl)
+
+
+class _Block(nn.Module):
+    """conv -> ComplexBatchNormal -> PReLU.  Eval mode: the running-statistics affine is folded into the
+    packed weights and PReLU runs in the conv epilogue (one kernel).  Train mode: the conv epilogue
+    emits the batch moments, then one finalise and one in-place normalise+PReLU kernel."""
+
+    def _run(self, conv, x: Planar, train: bool, **kw) -> Planar:
+        slope = self.prelu.weight.detach()
+        if train:
+            stats = torch.zeros(conv.out_channel, 5, dtype=torch.float64, device=x.buf.device)
+            y = conv.forward_planar(x, stats=stats, **kw)
+            return self.bn.finish_train(y, stats, slope)
+        return conv.forward_planar(x, fold=self.bn.eval_fold(), slope=slope, **kw)
+
+
+class Encoder(_Block):
+    """reference: model/pvae_module.py:45-68"""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride, chw, padding=None, causal=False):
+        super().__init__()
+        if padding is None:
+            padding = [int((k - 1) / 2) for k in kernel_size]
+        cls = causal_complex_conv2d if causal else ComplexConv2d
+        self.conv = cls(in_channel=in_channel, out_channel=out_channel, kernel_size=kernel_size, stride=stride,
+                        padding=padding)
+        self.bn = ComplexBatchNormal(chw[0], chw[1], chw[2])
+        self.prelu = nn.PReLU()
+
+    def forward_planar(self, x: Planar, train: bool) -> Planar:
+        return self._run(self.conv, x, train)
+
+    def forward(self, x, train):
+        return tag5(self.forward_planar(planar_of(x), train))
+
+
+class Decoder(_Block):
+    """reference: model/pvae_module.py:72-93"""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride, chw, padding=None, causal=False, if_bn=True):
+        super().__init__()
+        cls = causal_ComplexConvTranspose2d if causal else ComplexConvTranspose2d
+        self.transconv = cls(in_channel=in_channel, out_channel=out_channel, kernel_size=kernel_size, stride=stride,
+                             padding=padding)
+        self.bn = ComplexBatchNormal(chw[0], chw[1], chw[2])
+        self.prelu = nn.PReLU()
+        self.if_bn = if_bn
+
+    def forward_planar(self, x: Planar, train: bool = True, skip: Optional[Planar] = None, skip_div: int = 1,
+                       zero_skip: bool = False) -> Planar:
+        kw = dict(skip=skip, skip_div=skip_div, zero_skip=zero_skip)
+        if not self.if_bn:
+            return self.transconv.forward_planar(x, **kw)
+        return self._run(self.transconv, x, train, **kw)
+
+    def forward(self, x, train=True):
+        return tag5(self.forward_planar(planar_of(x), train))
+
+
+def _build_encoders(net_params, causal) -> nn.ModuleList:
+    ch = net_params["encoder_channels"]
+    return nn.ModuleList([
+        Encoder(in_channel=ch[i], out_channel=ch[i + 1], kernel_size=net_params["encoder_kernel_sizes"][i],
+                stride=net_params["encoder_strides"][i], padding=net_params["encoder_paddings"][i],
+                chw=net_params["encoder_chw"][i], causal=causal)
+        for i in range(len(ch) - 1)])
+
+
+def _build_decoders(net_params, causal, skip_to_use, use_sc=True) -> nn.ModuleList:
+    en, de = net_params["encoder_channels"], net_params["decoder_channels"]
+    blocks = []
+    for i in range(len(de) - 1):
+        cin = de[i] + (en[len(en) - 1 - i] if (use_sc and i in skip_to_use) else 0)
+        blocks.append(Decoder(in_channel=cin, out_channel=de[i + 1], kernel_size=net_params["decoder_kernel_sizes"][i],
+                              stride=net_params["decoder_strides"][i], padding=net_params["decoder_paddings"][i],
+                              chw=net_params["decoder_chw"][i], causal=causal))
+    return nn.ModuleList(blocks)
+
+
+def _run_encoders(encoders, x: Planar, train: bool) -> List[Planar]:
+    outs = []
+    for enc in encoders:
+        x = enc.forward_planar(x, train)
+        outs.append(x)
+    return outs
+
+
+def _lstm_out_view(lat: Planar, c0: int, c1: int) -> torch.Tensor:
+    v = lat.channel_slice(c0, c1)
+    v._idv = lat
+    v._idv_off = c0
+    return v
+
+
+class standard_DCCRN(nn.Module):
+    """reference: model/pvae_module.py:96-198"""
+
+    def __init__(self, net_params, causal, device, skip_to_use):
+        super().__init__()
+        self.device = device
+        self.causal = causal
+        self.skip_to_use = skip_to_use
+        self.dense = ComplexDense(net_params["dense"][0], net_params["dense"][1])
+        self.encoders = _build_encoders(net_params, causal)
+        dims = net_params["lstm_dim"]
+        self.lstms = nn.ModuleList([
+            ComplexLSTM(input_size=dims[i], hidden_size=dims[i + 1], num_layers=net_params["lstm_layer_num"], device=device)
+            for i in range(len(dims) - 1)])
+        self.decoders = _build_decoders(net_params, causal, skip_to_use)
+        self.linear = ComplexConv2d(in_channel=1, out_channel=1, kernel_size=1, stride=1)   # unused, kept for state_dict parity
+        self.detect_anormal = True
+
+    def forward_planar(self, x: Planar, train: bool = True) -> Planar:
+        skips = _run_encoders(self.encoders, x, train)
+        top = skips[-1]
+        lat = top
+        for lstm in self.lstms:
+            lat = lstm.forward_planar(lat)
+        if not train:
+            self.latent = _lstm_out_view(lat, 0, lat.C)            # [B, T, H, 2]
+        p = self.dense.forward_planar(lat, top.C, top.F)
+        for i, dec in enumerate(self.decoders):
+            p = dec.forward_planar(p, train, skip=skips[len(skips) - 1 - i] if i in self.skip_to_use else None)
+        return p
+
+    def forward(self, x, train=True):
+        return tag5(self.forward_planar(planar_of(x), train))
+
+
+def _apply_datanorm(stft: Planar, mean, std) -> Planar:
+    """Optional input normalisation of DCCRN_.forward (pvae_module.py:217-221); off in the shipped recipes."""
+    v = stft.tensor4()
+    out = Planar.empty(1, stft.F, stft.B, stft.T, stft.Tp, stft.buf.device, zero=True)
+    o = out.tensor4()
+    o.copy_((v - mean) / (std + 1e-6))
+    o[:, 0, :, 1] = 0
+    o[:, -1, :, 1] = 0
+    return out
+
+
+def _predict_outputs(module, out: Planar, stft_in: Planar, recon_type: str, x_div: int = 1):
+    """Mask / real_imag branch shared by DCCRN_ and the decoders -> (pred planar, predict complex [B,F,T])."""
+    if recon_type == "mask":
+        return ops.mask_apply(out, stft_in, x_div)
+    if recon_type == "real_imag":
+        return out, ops.planar_to_complex(out)
+    raise ValueError(f"recon_type {recon_type!r}")
+
+
+class DCCRN_(nn.Module):
+    """Supervised DCCRN (DCCRN-CL when causal=True).  reference: model/pvae_module.py:200-255.
+    forward(signal [B, L], train=True) -> (clean [B, hop*(T-1)], predict complex64 [B, F, T])."""
+
+    def __init__(self, n_fft, hop_len, net_params, causal, device, win_length, skip_to_use, recon_type, resynthesis,
+                 data_mean, data_std):
+        super().__init__()
+        self.stft = STFT(n_fft, hop_len, win_length=win_length, device=device)
+        self.std_DCCRN = standard_DCCRN(net_params, causal, device=device, skip_to_use=skip_to_use)
+        self.istft = ISTFT(n_fft, hop_len, win_length=win_length, device=device)
+        self.recon_type = recon_type
+        self.resynthesis = resynthesis
+        self.register_buffer("data_mean", data_mean)
+        self.register_buffer("data_std", data_std)
+        self.datanorm = self.data_mean is not None and self.data_std is not None
+
+    def forward(self, signal, train=True):
+        X = self.stft.planar(signal)
+        net_in = _apply_datanorm(X, self.data_mean, self.data_std) if self.datanorm else X
+        out = self.std_DCCRN.forward_planar(net_in, train=train)
+        pred, predict = _predict_outputs(self, out, net_in, self.recon_type)
+        if self.datanorm:
+            pr = torch.view_as_real(predict)
+            pr.copy_(self.data_std * pr + self.data_mean)
+            pred = Planar.from_tensor5(pr.unsqueeze(1), X.Tp)
+        clean = self.istft.planar(pred)
+        if self.resynthesis:
+            predict = ops.planar_to_complex(self.stft.planar(clean))
+        else:
+            predict._idv = pred
+        return clean, predict
+
+
+class _VAEEncoderBase(nn.Module):
+    """STFT -> 6 encoder blocks -> ComplexLSTM(1280 -> 3*zdim*latent_num) -> (miu | log_sigma | delta) per latent
+    -> reparameterised samples."""
+
+    def _setup(self, net_params, causal, device, zdim, n_fft, hop_len, win_length, num_samples, latent_num):
+        self.device = device
+        self.causal = causal
+        self.stft = STFT(n_fft, hop_len, win_length=win_length, device=device)
+        self.dense = ComplexDense(zdim, net_params["dense"][1])    # constructed and unused in the reference too
+        self.decoders = []
+        self.zdim = zdim
+        self.num_samples = num_samples
+        self.encoders = _build_encoders(net_params, causal)
+        dims = net_params["lstm_dim"]
+        hidden = int(3 * zdim * latent_num)
+        self.lstms = nn.ModuleList([
+            ComplexLSTM(input_size=dims[i], hidden_size=hidden, num_layers=net_params["lstm_layer_num"], device=device)
+            for i in range(len(dims) - 1)])
+        self.epsilon = 1e-6
+
+    def _sample(self, lat: Planar, k: int, eps) -> torch.Tensor:
+        """reparameterization (pvae_module.py:1832-1886) for latent k; eps = (eps_r, eps_i) or None."""
+        z = self.zdim
+        B, T, ns = lat.B, lat.T, self.num_samples
+        if eps is None:
+            eps = (torch.randn(B, ns, T, z, device=lat.buf.device), torch.randn(B, ns, T, z, device=lat.buf.device))
+        zp = ops.reparam(lat, (3 * z * k, 3 * z * k + z, 3 * z * k + 2 * z), z, eps[0], eps[1], ns)
+        v = zp.channel_slice(0, z)                                  # [B*ns, T, zdim, 2]
+        v._idv = zp
+        return v
+
+    def reparameterization(self, miu, log_sigma, delta, num_samples, eps=None):
+        """Stand-alone form with the reference's signature: miu/log_sigma/delta are [B, T, H, 2]."""
+        lat = torch.cat([miu, log_sigma, delta], dim=2).permute(0, 2, 1, 3).unsqueeze(2)
+        pl = Planar.from_tensor5(lat.float())
+        keep_ns, keep_z = self.num_samples, self.zdim
+        self.num_samples, self.zdim = num_samples, miu.shape[2]
+        try:
+            return self._sample(pl, 0, eps)
+        finally:
+            self.num_samples, self.zdim = keep_ns, keep_z
+
+    def _encode(self, x, train):
+        X = self.stft.planar(x)
+        skips = _run_encoders(self.encoders, X, train)
+        top = skips[-1]
+        lat = top
+        for lstm in self.lstms:
+            lat = lstm.forward_planar(lat)
+        stft_x = X.tensor4()
+        stft_x._idv = X
+        return lat, [tag5(s) for s in skips], top.C, top.F, stft_x
+
+
+class pvae_dccrn_encoder_skip_prepare(_VAEEncoderBase):
+    """CVAE / NVAE encoder.  reference: model/pvae_module.py:1791-1914.
+    forward(x, train=True, eps=None) -> (z, miu, log_sigma, delta, skiper, C, F, stft_x);
+    ``eps=(eps_r, eps_i)`` ([B, ns, T, zdim]) injects the two Gaussian draws (parity tests), default samples on device."""
+
+    def __init__(self, net_params, causal, device, zdim, n_fft, hop_len, win_length, num_samples):
+        super().__init__()
+        self._setup(net_params, causal, device, zdim, n_fft, hop_len, win_length, num_samples, 1)
+
+    def forward(self, x, train=True, eps=None):
+        lat, skiper, C, F, stft_x = self._encode(x, train)
+        z = self.zdim
+        return (self._sample(lat, 0, eps), _lstm_out_view(lat, 0, z), _lstm_out_view(lat, z, 2 * z),
+                _lstm_out_view(lat, 2 * z, 3 * z), skiper, C, F, stft_x)
+
+
+class nsvae_pvae_dccrn_encoder_twophase(_VAEEncoderBase):
+    """Noisy-speech (NSVAE) encoder.  reference: model/pvae_module.py:2131-2268.  forward -> 12-tuple
+    (z_speech, miu_speech, log_sigma_speech, delta_speech, z_noise, miu_noise, log_sigma_noise, delta_noise,
+    skiper, C, F, stft_x); eps = (eps_r_speech, eps_i_speech[, eps_r_noise, eps_i_noise])."""
+
+    def __init__(self, net_params, causal, device, zdim, n_fft, hop_len, win_length, num_samples, latent_num):
+        super().__init__()
+        if latent_num not in (1, 2):
+            raise ValueError("latent_num must be 1 or 2")
+        self.latent_num = latent_num
+        self._setup(net_params, causal, device, zdim, n_fft, hop_len, win_length, num_samples, latent_num)
+
+    def forward(self, x, train=True, eps=None):
+        lat, skiper, C, F, stft_x = self._encode(x, train)
+        z = self.zdim
+        out = []
+        for k in range(2):
+            if k < self.latent_num:
+                e = None if eps is None else (eps[2 * k], eps[2 * k + 1])
+                o = 3 * z * k
+                out += [self._sample(lat, k, e), _lstm_out_view(lat, o, o + z), _lstm_out_view(lat, o + z, o + 2 * z),
+                        _lstm_out_view(lat, o + 2 * z, o + 3 * z)]
+            else:
+                out += [None, None, None, None]
+        return (*out, skiper, C, F, stft_x)
+
+
+class _VAEDecoderBase(nn.Module):
+    def _setup(self, net_params, causal, device, num_samples, zdim, n_fft, hop_len, win_length, recon_type, skip_to_use,
+               use_sc=True):
+        self.device = device
+        self.causal = causal
+        self.num_samples = num_samples
+        self.zdim = zdim
+        self.recon_type = recon_type
+        self.skip_to_use = skip_to_use
+        self.use_sc = use_sc
+        self.dense = ComplexDense(zdim, net_params["dense"][1])
+        self.decoders = _build_decoders(net_params, causal, skip_to_use, use_sc)
+        self.istft = ISTFT(n_fft, hop_len, win_length=win_length, device=device)
+
+    def _decode(self, stft_x, z, skiper, C, F, train, pad):
+        zp = getattr(z, "_idv", None)
+        if zp is None:
+            _need_cuda(z)
+            zp = Planar.from_tensor5(z.permute(0, 2, 1, 3).unsqueeze(2).float())     # [Bn, zdim, 1, T, 2]
+        Bn = zp.B
+        p = self.dense.forward_planar(zp, C, F)
+        outs = []
+        for i, dec in enumerate(self.decoders):
+            if self.use_sc and i in self.skip_to_use:
+                if pad == "zero":
+                    p = dec.forward_planar(p, train, zero_skip=True)       # cat with zeros == half of K skipped
+                elif pad == "sig":
+                    sk = planar_of(skiper[len(skiper) - 1 - i], zp.Tp)
+                    if Bn % sk.B:
+                        raise RuntimeError("batch of z is not a multiple of the skip batch")
+                    p = dec.forward_planar(p, train, skip=sk, skip_div=Bn // sk.B)
+                else:
+                    raise ValueError(f"pad {pad!r}")
+            else:
+                p = dec.forward_planar(p, train)
+            outs.append(p)
+        X = planar_of(stft_x.unsqueeze(1), zp.Tp) if getattr(stft_x, "_idv", None) is None else stft_x._idv
+        pred, predict = _predict_outputs(self, p, X, self.recon_type, x_div=Bn // X.B)
+        recon = self.istft.planar(pred)
+        predict._idv = pred
+        return recon, predict, outs
+
+
+class pvae_dccrn_decoder_skip_prepare(_VAEDecoderBase):
+    """CVAE / NVAE decoder (skip inputs replaced by zeros).  reference: model/pvae_module.py:2045-2122.
+    forward(stft_x, z, skiper, C, F, train=True) -> (recon_sig [B*ns, L'], predict complex [B*ns, F, T])."""
+
+    def __init__(self, net_params, causal, device, num_samples, zdim, n_fft, hop_len, win_length, recon_type, skip_to_use):
+        super().__init__()
+        self._setup(net_params, causal, device, num_samples, zdim, n_fft, hop_len, win_length, recon_type, skip_to_use)
+
+    def forward(self, stft_x, z, skiper, C, F, train=True):
+        if self.recon_type != "real_imag":
+            raise ValueError("pvae_dccrn_decoder_skip_prepare implements recon_type='real_imag' (as the reference)")
+        recon, predict, outs = self._decode(stft_x, z, skiper, C, F, train, "zero")
+        self.decoder_outputs = [tag5(o) for o in outs]
+        return recon, predict
+
+
+class nsvae_pvae_dccrn_decoder_twophase(_VAEDecoderBase):
+    """Fine-tuned CVAE decoder.  reference: model/pvae_module.py:2505-2619.
+    forward(stft_x, z, skiper, C, F, train=True, pad='zero'|'sig') -> (recon_sig, predict)."""
+
+    def __init__(self, net_params, causal, device, num_samples, zdim, n_fft, hop_len, win_length, recon_type, use_sc,
+                 skip_to_use, resynthesis):
+        super().__init__()
+        self._setup(net_params, causal, device, num_samples, zdim, n_fft, hop_len, win_length, recon_type, skip_to_use,
+                    use_sc)
+        self.resynthesis = resynthesis
+        self.stft = STFT(n_fft, hop_len, win_length=win_length, device=device)
+
+    def forward(self, stft_x, z, skiper, C, F, train=True, pad="zero"):
+        recon, predict, _ = self._decode(stft_x, z, skiper, C, F, train, pad)
+        if self.resynthesis:
+            predict = ops.planar_to_complex(self.stft.planar(recon))
+        return recon, predict

@@ -302,3 +302,16 @@ def miu_dist(q1: Planar, off1: int, q2: Planar, off2: int, zdim: int) -> torch.T
     call("idv_miu_dist", q1.ptr(), i(q1.C), i(q1.Jp), i(off1), q2.ptr(), i(q2.C), i(q2.Jp), i(off2), i(zdim), i(q1.B), i(q1.T),
          i(q1.Tp), p(work), p(out), stream_ptr())
     return out[0]
+
+
+def cbn_stats(act: Planar) -> torch.Tensor:
+    """Moment sums [C][5] (double) of a planar activation, for a stand-alone train-mode batch norm."""
+    stats = torch.zeros(act.C, 5, dtype=torch.float64, device=act.buf.device)
+    call("idv_cbn_stats", act.ptr(), i(act.C), i(act.F), i(act.B), i(act.Tp), i(act.Jp), i(act.T), p(stats), stream_ptr())
+    return stats
+
+
+def cbn_apply(act: Planar, fold: torch.Tensor, slope=None):
+    call("idv_cbn_apply_prelu", act.ptr(), p(fold), p(slope), i(act.C), i(act.F), i(act.B), i(act.Tp), i(act.Jp), i(act.T),
+         stream_ptr())
+    return act

@@ -89,6 +89,9 @@ int idv_cbn_finalize(const double* stats, double count, const float* gamma_rr, c
                      const float* gamma_ii, const float* beta_r, const float* beta_i, int C, int first_call,
                      float momentum, float* running_mean_r, float* running_mean_i, float* Vrr, float* Vri,
                      float* Vii, float* moments, float* fold, void* stream);
+/* Moment sums of a planar activation (stand-alone ComplexBatchNormal.forward, complex_progress.py:131-143);
+ * stats [C][5] doubles, zeroed by the caller; same layout as the conv epilogue's. */
+int idv_cbn_stats(const float* act, int C, int F, int B, int Tp, int Jp, int t_valid, double* stats, void* stream);
 /* y = PReLU(Z*x + s) in place on a planar activation, guard columns stay zero. */
 int idv_cbn_apply_prelu(float* act, const float* fold, const float* prelu_slope, int C, int F, int B, int Tp, int Jp,
                         int t_valid, void* stream);

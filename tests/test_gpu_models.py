@@ -1,0 +1,208 @@
+"""End-to-end parity on the GPU: the drop-in nn.Modules (HIP path through the C ABI) against the golden
+vectors captured from the reference and against the CPU oracle.  north_star tolerance: 1e-3 relative on
+the enhanced waveform, frame indexing exact; we assert 1e-4 (fp32 MFMA)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr
+from oracle import idccrn_oracle as O
+
+pytestmark = pytest.mark.gpu
+NFFT, HOP, WIN = 512, 100, 400
+SKIP = [0, 1, 2, 3, 4, 5]
+WAVE_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def pm():
+    return importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+
+
+@pytest.fixture(scope="module")
+def losses():
+    return (importlib.import_module("i-dccrn-vae_amd.model.nsvae_loss"),
+            importlib.import_module("i-dccrn-vae_amd.model.pretrain_pvaes_loss"))
+
+
+def T_(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def load_synth(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    module.load_state_dict(O.synth_state_dict(shapes, seed), strict=True)
+    return module.cuda()
+
+
+@pytest.mark.parametrize("tag", ["mini_eval", "mini_train", "mini_noncausal_eval", "full_eval"])
+def test_dccrn_golden(pm, losses, golden, tag):
+    d = golden("dccrn_" + tag)
+    base, seed, train, causal = int(d["base"]), int(d["seed"]), bool(d["train"]), bool(d["causal"])
+    np_ = O.net_params(causal, base)
+    m = load_synth(pm.DCCRN_(NFFT, HOP, np_, causal, "cuda", WIN, SKIP, "mask", False, None, None), seed)
+    x = T_(d["x"]).cuda()
+    clean, predict = m(x, train=train)
+    want = T_(d["clean"])
+    assert tuple(clean.shape) == tuple(want.shape)                      # output length hop*(T-1): exact
+    assert predict.shape[1:] == (NFFT // 2 + 1, 1 + x.shape[1] // HOP) and predict.dtype == torch.complex64
+    assert relerr(clean.cpu(), want) < WAVE_TOL
+    pr = torch.view_as_real(predict).cpu()
+    if "pred" in d:
+        assert relerr(pr, T_(d["pred"])) < WAVE_TOL
+    else:
+        assert relerr(pr[:, ::8, ::16], T_(d["pred_sub"])) < WAVE_TOL
+        assert abs(float(pr.double().norm()) - float(d["pred_l2"])) < 1e-4 * float(d["pred_l2"])
+    if train:
+        sd = m.state_dict()
+        for k in d.files:
+            if k.startswith("bn:"):
+                assert relerr(sd[k[3:]].cpu(), T_(d[k])) < 1e-4, k
+    else:
+        assert relerr(m.std_DCCRN.latent.cpu(), T_(d["latent"])) < WAVE_TOL
+    # loss: final_ete_loss with weights 0/0/1 as in supervised_dccrn/train.sh
+    nl, _ = losses
+    clean_ref = T_(d["clean_ref"]).cuda()
+    L = nl.ete_train_se_loss([0.0, 0.0, 1.0])
+    got = L.final_ete_loss(predict, m.stft(clean_ref), clean_ref, clean)
+    got = torch.stack([g.float().cpu() for g in got])
+    want_l = T_(d["loss"])
+    for a, b in zip(got, want_l):
+        assert abs(float(a) - float(b)) < 2e-4 * max(1.0, abs(float(b)))
+
+
+def test_dccrn_vs_oracle_other_length(pm):
+    """Same module, another (odd) length and batch: parity against the CPU oracle directly."""
+    np_ = O.net_params(True, 4)
+    m = load_synth(pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None), 5)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 2345, generator=g) * 0.1
+    clean, predict = m(x.cuda(), train=False)
+    o_clean, o_pred, _ = O.dccrn_forward(x, sd, np_, True, NFFT, HOP, WIN, SKIP, "mask", False)
+    assert clean.shape == o_clean.shape == (3, HOP * (2345 // HOP))
+    assert relerr(clean.cpu(), o_clean) < WAVE_TOL
+    assert relerr(torch.view_as_real(predict).cpu(), o_pred) < WAVE_TOL
+    # real_imag reconstruction + resynthesis flag
+    m2 = load_synth(pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "real_imag", True, None, None), 5)
+    c2, p2 = m2(x.cuda(), train=False)
+    o_c2, _, _ = O.dccrn_forward(x, sd, np_, True, NFFT, HOP, WIN, SKIP, "real_imag", False)
+    assert relerr(c2.cpu(), o_c2) < WAVE_TOL
+    assert relerr(torch.view_as_real(p2).cpu(), O.stft(o_c2, NFFT, HOP, WIN)) < WAVE_TOL
+
+
+@pytest.mark.parametrize("tag", ["mini_eval", "mini_train"])
+def test_cvae_golden(pm, losses, golden, tag):
+    d = golden("vae_cvae_" + tag)
+    base, seed, zdim, ns, train = int(d["base"]), int(d["seed"]), int(d["zdim"]), int(d["ns"]), bool(d["train"])
+    np_ = O.net_params(True, base)
+    enc = load_synth(pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns), seed)
+    dec = load_synth(pm.pvae_dccrn_decoder_skip_prepare(np_, True, "cuda", ns, zdim, NFFT, HOP, WIN, "real_imag", SKIP), seed + 1)
+    x = T_(d["x"]).cuda()
+    eps = (T_(d["eps_r"]).cuda(), T_(d["eps_i"]).cuda())
+    z, miu, ls, dl, skiper, C, F, stft_x = enc(x, train=train, eps=eps)
+    assert (C, F) == (8 * base, 5) and len(skiper) == 6
+    for got, name in ((z, "z"), (miu, "miu"), (ls, "log_sigma"), (dl, "delta"), (skiper[5], "skip5")):
+        assert tuple(got.shape) == tuple(d[name].shape), name
+        assert relerr(got.cpu(), T_(d[name])) < WAVE_TOL, name
+    assert relerr(skiper[0][:, ::4, ::8, ::4].cpu(), T_(d["skip0_sub"])) < WAVE_TOL
+    recon, predict = dec(stft_x, z, skiper, C, F, train=train)
+    assert tuple(recon.shape) == tuple(d["recon"].shape)
+    assert relerr(recon.cpu(), T_(d["recon"])) < WAVE_TOL
+    assert relerr(torch.view_as_real(predict)[:, ::4, ::4].cpu(), T_(d["pred_sub"])) < WAVE_TOL
+    assert len(dec.decoder_outputs) == 6
+    # ELBO exactly as pretrained_vaes/train.py:283-292 calls it (materialised repeats)
+    _, pl = losses
+    bs, L = x.shape
+    xr = x[:, :recon.shape[1]].unsqueeze(1).repeat(1, ns, 1).view(bs * ns, -1)
+    sx = stft_x.unsqueeze(1).repeat(1, ns, 1, 1, 1).view(bs * ns, stft_x.shape[1], stft_x.shape[2], 2)
+    loss = pl.complex_standard_vae_loss(torch.ones(1), 1.0, 0.0, 'multiple', 'real_imag', [1.0, 1.0, 0.0], ns)
+    out = loss.cal_loss(xr, recon, sx, predict, miu, ls, dl, z, 5)
+    got = [out[0], out[1], out[2], out[4], out[5], out[6]]
+    for a, b in zip(got, T_(d["elbo"])):
+        assert abs(float(a) - float(b)) < 2e-4 * max(1.0, abs(float(b)))
+    # default path samples on the device (no injected eps): shapes only
+    z2 = enc(x, train=False)[0]
+    assert z2.shape == z.shape and torch.isfinite(z2).all()
+
+
+@pytest.mark.parametrize("tag", ["mini_eval", "mini_train"])
+def test_nsvae_twophase_golden(pm, losses, golden, tag):
+    d = golden("vae_nsvae_" + tag)
+    base, seed, zdim, ns, train = int(d["base"]), int(d["seed"]), int(d["zdim"]), int(d["ns"]), bool(d["train"])
+    np_ = O.net_params(True, base)
+    enc = load_synth(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns, 2), seed + 2)
+    dec = load_synth(pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, "cuda", ns, zdim, NFFT, HOP, WIN, "mask", True, SKIP, False), seed + 3)
+    x = T_(d["x"]).cuda()
+    eps = tuple(T_(d[f"eps{i}"]).cuda() for i in range(4))
+    r = enc(x, train=train, eps=eps)
+    assert len(r) == 12
+    z_s, miu_s, ls_s, dl_s, z_n, miu_n, ls_n, dl_n, skiper, C, F, stft_x = r
+    for got, name in ((z_s, "z_speech"), (z_n, "z_noise"), (miu_s, "miu_speech"), (miu_n, "miu_noise"),
+                      (ls_s, "log_sigma_speech"), (ls_n, "log_sigma_noise"), (dl_s, "delta_speech"), (dl_n, "delta_noise")):
+        assert relerr(got.cpu(), T_(d[name])) < WAVE_TOL, name
+    recon, predict = dec(stft_x, z_s, skiper, C, F, train=train, pad='sig')
+    assert relerr(recon.cpu(), T_(d["recon"])) < WAVE_TOL
+    assert relerr(torch.view_as_real(predict)[:, ::4, ::4].cpu(), T_(d["pred_sub"])) < WAVE_TOL
+    nl, _ = losses
+    bs = x.shape[0]
+    xr = x[:, :recon.shape[1]].unsqueeze(1).repeat(1, ns, 1).view(bs * ns, -1)
+    sx = stft_x.unsqueeze(1).repeat(1, ns, 1, 1, 1).view(bs * ns, stft_x.shape[1], stft_x.shape[2], 2)
+    tl = nl.two_phase_loss([0, 0, 1], 1.0, zdim, 1)
+    got = tl.phase_2_loss(predict, sx, xr, recon, None, None, None, None)
+    for a, b in zip(got[:4], T_(d["phase2"])):
+        assert abs(float(a) - float(b)) < 2e-4 * max(1.0, abs(float(b)))
+    # latent_num = 1 returns None for the noise latent
+    enc1 = load_synth(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns, 1), seed)
+    r1 = enc1(x, train=False)
+    assert r1[4] is None and r1[5] is None and r1[0].shape == z_s.shape
+
+
+def test_nsvae_loss_from_encoders(pm, losses):
+    """config 3 call sequence (train_nsvae.py:487-544): two frozen skip_prepare encoders + the twophase encoder,
+    then standard_nsvae_loss_true_kl.final_nsvae_loss - against the oracle on the same latents."""
+    nl, _ = losses
+    base, zdim, ns = 4, 16, 2
+    np_ = O.net_params(True, base)
+    ce = load_synth(pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns), 61)
+    ne = load_synth(pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns), 62)
+    se = load_synth(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns, 2), 63)
+    g = torch.Generator().manual_seed(3)
+    clean, noise = torch.randn(2, 1600, generator=g) * 0.1, torch.randn(2, 1600, generator=g) * 0.1
+    c = ce(clean.cuda(), train=False)
+    n = ne(noise.cuda(), train=False)
+    s = se((clean + noise).cuda(), train=True)
+    loss = nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.5, zdim, ns, 2, 'original', 'False', SKIP, 'both')
+    out = loss.final_nsvae_loss(c[1], n[1], s[1], s[5], c[2], n[2], s[2], s[6], c[3], n[3], s[3], s[7], s[0], s[4],
+                                c[4], n[4], s[8])
+    cpu = lambda t: t.cpu()
+    want = O.nsvae_loss(cpu(c[1]), cpu(n[1]), cpu(s[1]), cpu(s[5]), cpu(c[2]), cpu(n[2]), cpu(s[2]), cpu(s[6]),
+                        cpu(c[3]), cpu(n[3]), cpu(s[3]), cpu(s[7]), 1.0, 1.0, 0.5, 2)
+    for a, b in zip(out[:6], want):
+        assert abs(float(a) - float(b)) < 2e-4 * max(1.0, abs(float(b)))
+
+
+def test_state_dict_roundtrip_and_repack(pm):
+    """Weights are re-packed when parameters change in place (optimizer step / load_state_dict)."""
+    np_ = O.net_params(True, 4)
+    m = load_synth(pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None), 5)
+    x = (torch.randn(1, 1600, generator=torch.Generator().manual_seed(0)) * 0.1).cuda()
+    a, _ = m(x, train=False)
+    b, _ = m(x, train=False)
+    assert torch.equal(a, b)                                           # deterministic, cached pack
+    with torch.no_grad():
+        m.std_DCCRN.encoders[0].conv.conv_re.weight.mul_(1.5)
+    c, _ = m(x, train=False)
+    assert not torch.equal(a, c)
+    m.load_state_dict(O.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 5))
+    d, _ = m(x, train=False)
+    assert torch.equal(a, d)
+
+
+def test_cpu_tensor_is_rejected(pm):
+    np_ = O.net_params(True, 4)
+    m = pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None).cuda()
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(torch.zeros(1, 1600))
