@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 4 s @ 16 kHz utterances/sec, forward + SI-SNR, DCCRN-CL, on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One step = one pass of the hot path over one batch of synthetic utterances resident in HBM:
+  DCCRN_(causal, skips 012345, mask).forward(noisy, train=False)  ->  ete_train_se_loss([0,0,1]).final_ete_loss
+  (STFT -> 6 complex-conv encoder blocks -> complex LSTM -> dense -> 6 complex transposed-conv decoder blocks
+   -> mask -> ISTFT, + STFT(clean) + STFT losses + SI-SNR), i.e. supervised_dccrn/train.py:233-237 of the reference
+  without the backward pass.  Utterances are independent: each rank runs its own batch (replicas, no collective
+  on the data path); value = all ranks' utterances / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant cgemm instantiation, HIP-event timed on the launching
+stream inside the timed region) and `cpu_baseline` (the torch-CPU oracle on the host cores, N = 1 only).
+Other workloads: --workload cvae_elbo | nsvae_kl | twophase (BASELINE.json configs 2, 3, 5, forward + loss).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NFFT, HOP, WIN, LEN = 512, 100, 400, 64000
+SKIP = [0, 1, 2, 3, 4, 5]
+PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+METRIC = "4s@16kHz utterances/sec fwd+SI-SNR, DCCRN-CL, 1/2/4/8 MI355X vs host CPU"
+
+
+def synth_state(module, seed):
+    synth = importlib.import_module("i-dccrn-vae_amd.utils.synth")
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    module.load_state_dict(synth.synth_state_dict(shapes, seed), strict=True)
+    return module
+
+
+def make_inputs(B, seed, device):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    clean = torch.randn(B, LEN, generator=g) * 0.1
+    g2 = torch.Generator().manual_seed(seed + 1)
+    noise = torch.randn(B, LEN, generator=g2) * 0.1
+    return (clean + noise).to(device), clean.to(device), noise.to(device)
+
+
+def build_workload(name, B, device, rank):
+    """-> (step callable, utterances per step, description dict)"""
+    import torch
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    nl = importlib.import_module("i-dccrn-vae_amd.model.nsvae_loss")
+    pl = importlib.import_module("i-dccrn-vae_amd.model.pretrain_pvaes_loss")
+    cn = importlib.import_module("i-dccrn-vae_amd.model.causal_netconfig")
+    np_ = cn.get_net_params()
+    noisy, clean, noise = make_inputs(B, 123 + 1000 * rank, device)
+    if name == "dccrn_cl":
+        model = synth_state(pm.DCCRN_(NFFT, HOP, np_, True, device, WIN, SKIP, "mask", False, None, None), 51).to(device)
+        loss = nl.ete_train_se_loss([0.0, 0.0, 1.0])
+
+        def step():
+            est, est_stft = model(noisy, train=False)
+            return loss.final_ete_loss(est_stft, model.stft(clean), clean, est)[0]
+        return step, B, {"workload": "supervised DCCRN-CL forward(train=False) + final_ete_loss (weights 0/0/1)",
+                         "batch_per_gpu": B}
+    if name == "cvae_elbo":
+        ns, zdim = 5, 128
+        enc = synth_state(pm.pvae_dccrn_encoder_skip_prepare(np_, True, device, zdim, NFFT, HOP, WIN, ns), 52).to(device)
+        dec = synth_state(pm.pvae_dccrn_decoder_skip_prepare(np_, True, device, ns, zdim, NFFT, HOP, WIN, "real_imag", SKIP), 53).to(device)
+        loss = pl.complex_standard_vae_loss(torch.ones(1), 1.0, 0.0, 'multiple', 'real_imag', [1.0, 1.0, 0.0], ns)
+
+        def step():
+            z, miu, ls, dl, skiper, C, F, stft_x = enc(clean, train=False)
+            recon, pred = dec(stft_x, z, skiper, C, F, train=False)
+            return loss.cal_loss(clean, recon, stft_x, pred, miu, ls, dl, z, 100)[0]
+        return step, B, {"workload": "pretrained CVAE forward (eval BN) + ELBO, num_samples=5", "batch_per_gpu": B}
+    if name == "nsvae_kl":
+        ns, zdim = 2, 128
+        ce = synth_state(pm.pvae_dccrn_encoder_skip_prepare(np_, True, device, zdim, NFFT, HOP, WIN, ns), 54).to(device)
+        ne = synth_state(pm.pvae_dccrn_encoder_skip_prepare(np_, True, device, zdim, NFFT, HOP, WIN, ns), 55).to(device)
+        se = synth_state(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, device, zdim, NFFT, HOP, WIN, ns, 2), 56).to(device)
+        loss = nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.0, zdim, ns, 2, 'original', 'False', SKIP, 'both')
+
+        def step():
+            c = ce(clean, train=False)
+            n = ne(noise, train=False)
+            s = se(noisy, train=False)
+            return loss.final_nsvae_loss(c[1], n[1], s[1], s[5], c[2], n[2], s[2], s[6], c[3], n[3], s[3], s[7],
+                                         s[0], s[4], c[4], n[4], s[8])[0]
+        return step, B, {"workload": "NSVAE: 2 frozen CVAE/NVAE encoders + noisy encoder (latent_num=2) + nsvae KL loss",
+                         "batch_per_gpu": B}
+    if name == "twophase":
+        ns, zdim = 2, 128
+        se = synth_state(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, device, zdim, NFFT, HOP, WIN, ns, 2), 56).to(device)
+        dec = synth_state(pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, device, ns, zdim, NFFT, HOP, WIN, "mask", True, SKIP, False), 57).to(device)
+        loss = nl.two_phase_loss([0, 0, 1], 1.0, zdim, 1)
+
+        def step():
+            s = se(noisy, train=False)
+            recon, pred = dec(s[11], s[0], s[8], s[9], s[10], train=False, pad='sig')
+            return loss.phase_2_loss(pred, s[11], clean, recon, None, None, None, None)[0]
+        return step, B, {"workload": "two-phase decoder fine-tune forward: frozen NSVAE encoder + decoder(mask, pad='sig') + SI-SNR",
+                         "batch_per_gpu": B}
+    raise SystemExit(f"unknown workload {name}")
+
+
+def host_cores() -> int:
+    """CPU share of this process (the GPU box exposes more logical CPUs than the job may use)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("IDV_CPU_THREADS", "16"))))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (torch-CPU restatement of the reference's op sequence, MKLDNN convolutions, all host
+    cores) on a bounded sample of the SAME workload: B = 2 utterances per pass."""
+    import torch
+    from oracle import idccrn_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    np_ = O.net_params(True, 32)
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    m = pm.DCCRN_(NFFT, HOP, np_, True, "cpu", WIN, SKIP, "mask", False, None, None)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = O.synth_state_dict(shapes, 51)
+    B = 2
+    noisy, clean, _ = make_inputs(B, 123, "cpu")
+
+    def one():
+        with torch.no_grad():
+            est, pred, _ = O.dccrn_forward(noisy, sd, np_, True, NFFT, HOP, WIN, SKIP, "mask", False)
+            return O.multiple_recon_loss(pred, O.stft(clean, NFFT, HOP, WIN), clean, est, [0.0, 0.0, 1.0])[0]
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 24:
+            break
+    return {"value": round(B * n / el, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} passes of B={B} 4 s utterances, DCCRN-CL forward + final_ete_loss, torch-CPU oracle "
+                      f"(oracle/idccrn_oracle.py), {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--workload", default="dccrn_cl")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    ops = importlib.import_module("i-dccrn-vae_amd").ops
+    torch.set_grad_enabled(False)
+    step, utt_per_step, cfg = build_workload(args.workload, args.batch, device, rank)
+
+    log(f"workload {args.workload} B={args.batch} built; warmup {args.warmup}")
+    for w in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warmup step {w} done")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    ops.LAUNCH_LOG = []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    loss_val = float(last)
+    log(f"timed {args.steps} steps in {elapsed:.3f} s")
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    # dominant kernel: group conv launches by cgemm instantiation, HIP-event durations on the launch stream
+    groups = {}
+    for cfg_id, macs, e0, e1 in launches:
+        g = groups.setdefault(cfg_id, [0, 0.0, 0])
+        g[0] += macs
+        g[1] += e0.elapsed_time(e1) * 1e-3
+        g[2] += 1
+    roofline = None
+    if groups:
+        dom = max(groups, key=lambda k: groups[k][1])
+        macs, secs, n = groups[dom]
+        tot_macs = sum(g[0] for g in groups.values())
+        tot_secs = sum(g[1] for g in groups.values())
+        d = str(dom)
+        mode = "TCONV" if len(d) == 7 else "CONV"
+        t = d[-6:]
+        roofline = {
+            "bound": "mfma", "achieved": round(2 * macs / secs / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(2 * macs / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": f"cgemm_kernel<{mode}, WM={t[0]}, WN={t[1]}, MT_W={t[2]}, FO_T={t[3]}, JC_W={t[4]}, CCK={t[5]}>",
+            "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
+            "algorithmic_gflop_per_launch": round(2 * macs / n / 1e9, 3),
+            "all_conv_launches": {"achieved": round(2 * tot_macs / tot_secs / 1e12, 3),
+                                  "frac": round(2 * tot_macs / tot_secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "share_of_step_time": round(tot_secs / elapsed, 4)},
+            "per_kernel": {str(k): {"tflops": round(2 * v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / args.steps * 1e3, 3)}
+                           for k, v in sorted(groups.items())},
+        }
+
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": round(world * utt_per_step * args.steps / elapsed, 3), "unit": "utterances/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (0.1*N(0,1) clean + noise, seeded; random-init weights)",
+            "config": dict(cfg, utterance="4 s @ 16 kHz (64000 samples, 641 frames)", parallelism=f"replicas x{world}",
+                           loss=loss_val),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "dccrn_cl":
+            log("cpu baseline ...")
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,25 +23,40 @@ int launch_cfg(const CgemmArgs& a, hipStream_t st) {
 
 inline int waste(int n, int t) { return ((n + t - 1) / t) * t - n; }
 
-template <bool STATS>
-int launch_conv(const CgemmArgs& a, int mode, hipStream_t st) {
-    const int CC = 2 * (a.C0 + a.C1);
-    const int rows = (mode == IDV_TCONV) ? a.Fin : a.Fout;
+// configuration id = the template arguments <MODE, WM, WN, MT_W, FO_T, JC_W, CCK> as decimal digits
+int conv_config(int mode, int CC, int M, int rows) {
     const bool fo5 = waste(rows, 5) <= waste(rows, 3);
     if (mode == IDV_CONV) {
-        if (CC % 4 != 0) return launch_cfg<IDV_CONV, 2, 2, 1, 3, 3, 2, false, STATS>(a, st);
-        if (fo5) return launch_cfg<IDV_CONV, 2, 2, 1, 5, 2, 4, false, STATS>(a, st);
-        return launch_cfg<IDV_CONV, 2, 2, 1, 3, 3, 4, false, STATS>(a, st);
+        if (CC % 4 != 0) return 221332;
+        return fo5 ? 221524 : 221334;
     }
-    if (CC % 4 != 0) return IDV_EINVAL;
-    if (a.M <= 32) return launch_cfg<IDV_TCONV, 1, 4, 1, 3, 1, 4, false, STATS>(a, st);
-    if (fo5) return launch_cfg<IDV_TCONV, 2, 2, 1, 5, 1, 4, false, STATS>(a, st);
-    return launch_cfg<IDV_TCONV, 2, 2, 1, 3, 2, 4, false, STATS>(a, st);
+    if (CC % 4 != 0) return -1;
+    if (M <= 32) return 1141314;
+    return fo5 ? 1221514 : 1221324;
+}
+
+template <bool STATS>
+int launch_conv(const CgemmArgs& a, int mode, hipStream_t st) {
+    const int rows = (mode == IDV_TCONV) ? a.Fin : a.Fout;
+    switch (conv_config(mode, 2 * (a.C0 + a.C1), a.M, rows)) {
+        case 221332: return launch_cfg<IDV_CONV, 2, 2, 1, 3, 3, 2, false, STATS>(a, st);
+        case 221524: return launch_cfg<IDV_CONV, 2, 2, 1, 5, 2, 4, false, STATS>(a, st);
+        case 221334: return launch_cfg<IDV_CONV, 2, 2, 1, 3, 3, 4, false, STATS>(a, st);
+        case 1141314: return launch_cfg<IDV_TCONV, 1, 4, 1, 3, 1, 4, false, STATS>(a, st);
+        case 1221514: return launch_cfg<IDV_TCONV, 2, 2, 1, 5, 1, 4, false, STATS>(a, st);
+        case 1221324: return launch_cfg<IDV_TCONV, 2, 2, 1, 3, 2, 4, false, STATS>(a, st);
+        default: return IDV_EINVAL;
+    }
 }
 
 }  // namespace
 
 extern "C" int idv_cconv_cck(int cin_used) { return ((2 * cin_used) % 4 == 0) ? 4 : 2; }
+
+extern "C" int idv_cconv_config(int transposed, int cin_used, int Cout, int Fin) {
+    const int rows = transposed ? Fin : (Fin - 1) / 2 + 1;
+    return conv_config(transposed ? IDV_TCONV : IDV_CONV, 2 * cin_used, 2 * Cout, rows);
+}
 
 extern "C" int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div,
                                const float* wfrag, const float* bias, const float* prelu_slope, float* out,

@@ -118,6 +118,11 @@ def pack_pw(w, bias):
 
 
 # ----------------------------------------------------------------------------- forward ops
+# When set to a list, every cconv2d launch appends (config id, algorithmic MACs, start event, end event);
+# bench.py uses it to time the dominant kernel with events on the launching stream.
+LAUNCH_LOG = None
+
+
 def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True, slope=None, skip: Optional[Planar] = None,
             skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None) -> Planar:
     """(causal_)ComplexConv2d / (causal_)ComplexConvTranspose2d forward on planar activations."""
@@ -130,9 +135,20 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
     if out is None:
         out = Planar.empty(cout, Fout, x.B, t_out, x.Tp, x.buf.device)
     c1 = skip.C if skip is not None else 0
+    if LAUNCH_LOG is not None:
+        cfg = L.lib().idv_cconv_config(i(1 if transposed else 0), i(x.C + c1), i(cout), i(x.F))
+        # algorithmic MACs: 4 real convolutions of the reference, kernel 5x2, per kept output position
+        # (transposed: per INPUT position, each input feeds 5x2 taps)
+        pos = x.B * x.T * (x.F if transposed else Fout)
+        macs = 4 * (x.C + c1) * cout * 10 * pos
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     call("idv_cconv2d_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
          i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag), p(bias), p(slope), out.ptr(), p(stats),
          i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+    if LAUNCH_LOG is not None:
+        ev1.record()
+        LAUNCH_LOG.append((cfg, macs, ev0, ev1))
     return out
 
 

@@ -29,6 +29,10 @@ int idv_abi_version(void);
 /* K-chunk (in planar channels) the contraction kernel uses for `cin_used` complex input channels;
  * wfrag for a complex conv holds  roundup(2*Cout,128)/32 * roundup(2*cin_used, cck)*5 * 64 floats. */
 int idv_cconv_cck(int cin_used);
+/* Which cgemm_kernel instantiation idv_cconv2d_fwd launches for a layer shape: the template arguments
+ * <MODE, WM, WN, MT_W, FO_T, JC_W, CCK> written as decimal digits (e.g. 1221324), -1 if unsupported.
+ * Lets bench.py / profiles name the kernel a measured launch belongs to. */
+int idv_cconv_config(int transposed, int cin_used, int Cout, int Fin);
 
 /* ComplexBatchNormal statistics -> affine: model/complex_progress.py:168-209 (cbn).
  * moments: [5][C] = mean_r, mean_i, Vrr, Vri, Vii (Vrr/Vii already carry +1e-5, as the reference's
