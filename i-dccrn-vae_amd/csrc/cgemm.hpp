@@ -95,37 +95,35 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
 
+    // ---- staging: global -> registers (issued before the chunk's MFMAs) -> LDS (after them) ----------
     float stg[NLD];
     auto stage_load = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * NT;
-            float v = 0.f;
-            if (e < NE) {
-                const int row = e / PS, col = e - row * PS;
-                const int ccl = row / FR, fr = row - ccl * FR;
-                const int cc = chunk * CCK + ccl;
-                const int fi = fbase + fr;
-                const int j = j0 - 1 + col;
-                if (cc < CC && fi >= 0 && fi < a.Fin && j >= 0 && j < a.J) {
-                    if (MODE == IDV_PW) {
-                        v = a.x0[(size_t)cc * a.Jp + j];
-                    } else {
-                        const int ci = cc >> 1, ri = cc & 1;
-                        if (ci < a.C0) {
-                            v = a.x0[((size_t)(ri * a.C0 + ci) * a.Fin + fi) * a.Jp + j];
-                        } else {
-                            int js = j;
-                            if (a.x1_div > 1) {
-                                const int b = j / a.Tp;
-                                js = j - (b - b / a.x1_div) * a.Tp;
-                            }
-                            v = a.x1[((size_t)(ri * a.C1 + (ci - a.C0)) * a.Fin + fi) * a.Jp1 + js];
-                        }
+            const int row = e / PS, col = e - row * PS;
+            const int ccl = row / FR, fr = row - ccl * FR;
+            const int cc = chunk * CCK + ccl;
+            const int fi = fbase + fr;
+            const int j = j0 - 1 + col;
+            const bool ok = (e < NE) && (cc < CC) && (fi >= 0) && (fi < a.Fin) && (j >= 0) && (j < a.J);
+            const float* src = a.x0;                       // masked lanes: the always-zero guard element
+            if (MODE == IDV_PW) {
+                if (ok) src = a.x0 + (size_t)cc * a.Jp + j;
+            } else {
+                const int ci = cc >> 1, ri = cc & 1;
+                if (ci < a.C0) {
+                    if (ok) src = a.x0 + ((size_t)(ri * a.C0 + ci) * a.Fin + fi) * a.Jp + j;
+                } else {
+                    int js = j;
+                    if (a.x1_div > 1) {
+                        const int b = j / a.Tp;
+                        js = j - (b - b / a.x1_div) * a.Tp;
                     }
+                    if (ok) src = a.x1 + ((size_t)(ri * a.C1 + (ci - a.C0)) * a.Fin + fi) * a.Jp1 + js;
                 }
             }
-            stg[i] = v;
+            stg[i] = *src;      // masked lanes read x0[0]: the tp == 0 guard column, zero by the layout invariant
         }
     };
     auto stage_store = [&](float* dst) {
@@ -136,54 +134,96 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
         }
     };
 
+    // ---- weight fragments: one coalesced 256 B load per (k-step, row tile), a whole chunk ahead -------
     const float* wbase = a.wfrag + (size_t)mt0 * KS * 64 + lane;
-    const int bcol = wn * (JC_W * 32) + (lane & 31) + (lane >> 5) + 1 + a.tshift;
+    float a_cur[KSC][MT_W], a_nxt[KSC][MT_W];
+    auto load_a = [&](int chunk, float (&dst)[KSC][MT_W]) {
+        const float* wch = wbase + (size_t)chunk * KSC * 64;
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT_W; ++i) dst[ks][i] = wch[((size_t)i * KS + ks) * 64];
+    };
+
+    // ---- activation fragments: all patch rows one plane (PW: one plane pair) needs, one unit ahead -----
+    constexpr int UNITS = (MODE == IDV_PW) ? CCK / 2 : CCK;      // pipeline units per chunk
+    const int bcol = wn * (JC_W * 32) + (lane & 31) + ((MODE == IDV_PW) ? 1 : (lane >> 5) + 1 + a.tshift);
+    auto load_b = [&](const float* P, int u, float (&dst)[FR][JC_W]) {
+#pragma unroll
+        for (int fr = 0; fr < FR; ++fr)
+#pragma unroll
+            for (int jc = 0; jc < JC_W; ++jc) {
+                if (MODE == IDV_PW)
+                    dst[fr][jc] = P[(2 * u + (lane >> 5)) * PS + bcol + jc * 32];
+                else
+                    dst[fr][jc] = P[(u * FR + fr) * PS + bcol + jc * 32];
+            }
+    };
 
     stage_load(0);
+    load_a(0, a_cur);
     stage_store(smem);
+    // Retire the prologue's weight loads before the loop: otherwise the loop header inherits them as
+    // "pending" and hipcc puts counted vmcnt waits in front of the loop's MFMAs, which in steady state
+    // wait for the NEXT chunk's prefetch (a false dependency worth ~1 us per chunk).
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+        for (int i = 0; i < MT_W; ++i) asm volatile("" : "+v"(a_cur[ks][i]));
     __syncthreads();
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const float* P = smem + (chunk & 1) * NE;
-        if (chunk + 1 < nchunk) stage_load(chunk + 1);
-
-        const float* wch = wbase + (size_t)chunk * KSC * 64;
+        const bool more = chunk + 1 < nchunk;
+        if (more) {
+            stage_load(chunk + 1);
+            load_a(chunk + 1, a_nxt);
+        }
+        float b_cur[FR][JC_W], b_nxt[FR][JC_W];
+        load_b(P, 0, b_cur);
 #pragma unroll
-        for (int ks = 0; ks < KSC; ++ks) {
-            float af[MT_W];
+        for (int u = 0; u < UNITS; ++u) {
+            if (u + 1 < UNITS) load_b(P, u + 1, b_nxt);
+            __builtin_amdgcn_sched_barrier(0);        // keep the next unit's LDS reads ahead of this unit's MFMAs
 #pragma unroll
-            for (int i = 0; i < MT_W; ++i) af[i] = wch[((size_t)i * KS + ks) * 64];
-            const int ccl = (MODE == IDV_PW) ? 2 * ks : ks / KF;
-            const int kf = (MODE == IDV_PW) ? 0 : ks % KF;
+            for (int kf = 0; kf < KF; ++kf) {
+                const int ks = (MODE == IDV_PW) ? u : u * KF + kf;
 #pragma unroll
-            for (int rt = 0; rt < ROWS; ++rt) {
-                int fr;
-                if (MODE == IDV_CONV) {
-                    fr = 2 * rt + kf;
-                } else if (MODE == IDV_TCONV) {
-                    if ((rt & 1) != (kf & 1)) continue;       // even rows take even taps, odd rows odd taps
-                    fr = (rt >> 1) + 2 - (kf >> 1);
-                } else {
-                    fr = 0;
-                }
-#pragma unroll
-                for (int jc = 0; jc < JC_W; ++jc) {
-                    float bf;
-                    if (MODE == IDV_PW)
-                        bf = P[(ccl + (lane >> 5)) * PS + wn * (JC_W * 32) + jc * 32 + (lane & 31) + 1];
-                    else
-                        bf = P[(ccl * FR + fr) * PS + bcol + jc * 32];
-#pragma unroll
-                    for (int i = 0; i < MT_W; ++i) {
-                        if (SWAP)
-                            acc[i][rt * JC_W + jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf, af[i], acc[i][rt * JC_W + jc], 0, 0, 0);
-                        else
-                            acc[i][rt * JC_W + jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf, acc[i][rt * JC_W + jc], 0, 0, 0);
+                for (int rt = 0; rt < ROWS; ++rt) {
+                    int fr;
+                    if (MODE == IDV_CONV) {
+                        fr = 2 * rt + kf;
+                    } else if (MODE == IDV_TCONV) {
+                        if ((rt & 1) != (kf & 1)) continue;       // even rows take even taps, odd rows odd taps
+                        fr = (rt >> 1) + 2 - (kf >> 1);
+                    } else {
+                        fr = 0;
                     }
+#pragma unroll
+                    for (int jc = 0; jc < JC_W; ++jc)
+#pragma unroll
+                        for (int i = 0; i < MT_W; ++i) {
+                            if (SWAP)
+                                acc[i][rt * JC_W + jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[fr][jc], a_cur[ks][i], acc[i][rt * JC_W + jc], 0, 0, 0);
+                            else
+                                acc[i][rt * JC_W + jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ks][i], b_cur[fr][jc], acc[i][rt * JC_W + jc], 0, 0, 0);
+                        }
                 }
             }
+            if (u + 1 < UNITS) {
+#pragma unroll
+                for (int fr = 0; fr < FR; ++fr)
+#pragma unroll
+                    for (int jc = 0; jc < JC_W; ++jc) b_cur[fr][jc] = b_nxt[fr][jc];
+            }
         }
-        if (chunk + 1 < nchunk) stage_store(smem + ((chunk + 1) & 1) * NE);
+        if (more) {
+            stage_store(smem + ((chunk + 1) & 1) * NE);
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT_W; ++i) a_cur[ks][i] = a_nxt[ks][i];
+        }
         __syncthreads();
     }
 
@@ -197,6 +237,12 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
 #pragma unroll
         for (int i = 0; i < MT_W; ++i) {
             const int mt = mt0 + i;
+            float bia[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                bia[r] = a.bias[m];                 // bias is allocated (zero padded) for every row of every tile
+            }
             // train-mode moments: registers (2q, 2q+1) hold (real, imag) of one channel
             float st[STATS ? 8 : 1][5];
             if (STATS) {
@@ -220,7 +266,7 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float t = v[r] + ((m < a.M) ? a.bias[m] : 0.f);
+                        float t = v[r] + bia[r];
                         if (has_act) t = t >= 0.f ? t : slope * t;
                         y[r] = keep ? t : 0.f;
                         if (m < a.M && inb) {
