@@ -4,21 +4,31 @@
 
 namespace {
 
-template <int MODE, int WM, int WN, int MT_W, int FO_T, int JC_W, int CCK, bool SWAP, bool STATS>
-int launch_cfg(const CgemmArgs& a, hipStream_t st) {
+template <int MODE, int WM, int WN, int MT_W, int FO_T, int JC_W, int CCK, bool SWAP, bool STATS, bool VEC>
+int launch_vec(const CgemmArgs& a, hipStream_t st) {
     using G = CgemmGeom<MODE, FO_T>;
     constexpr int JT = 32 * JC_W * WN;
-    constexpr int NE = CCK * G::FR * (JT + 2);
+    constexpr int NE = CCK * G::FR * (VEC ? JT + 8 : JT + 2);
     constexpr size_t smem = 2 * NE * sizeof(float);
     const int rows = (MODE == IDV_TCONV) ? a.Fin : a.Fout;          // TCONV tiles over input rows m
     dim3 grid((a.J + JT - 1) / JT, (rows + FO_T - 1) / FO_T, ((a.M + 31) / 32 + WM * MT_W - 1) / (WM * MT_W));
-    auto k = cgemm_kernel<MODE, WM, WN, MT_W, FO_T, JC_W, CCK, SWAP, STATS>;
+    auto k = cgemm_kernel<MODE, WM, WN, MT_W, FO_T, JC_W, CCK, SWAP, STATS, VEC>;
     if (smem > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return IDV_ELAUNCH;
     }
     hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), smem, st, a);
     return idv_launch_status();
+}
+
+// vector staging needs 16-byte aligned rows and the same column mapping for both sources
+template <int MODE, int WM, int WN, int MT_W, int FO_T, int JC_W, int CCK, bool SWAP, bool STATS>
+int launch_cfg(const CgemmArgs& a, hipStream_t st) {
+    const bool vec = (a.Jp % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x0) & 15) == 0) &&
+                     (a.C1 == 0 || (a.x1_div == 1 && a.Jp1 == a.Jp && (reinterpret_cast<uintptr_t>(a.x1) & 15) == 0)) &&
+                     (MODE == IDV_PW || (2 * a.C0) % CCK == 0);
+    if (vec) return launch_vec<MODE, WM, WN, MT_W, FO_T, JC_W, CCK, SWAP, STATS, true>(a, st);
+    return launch_vec<MODE, WM, WN, MT_W, FO_T, JC_W, CCK, SWAP, STATS, false>(a, st);
 }
 
 inline int waste(int n, int t) { return ((n + t - 1) / t) * t - n; }

@@ -56,15 +56,22 @@ struct CgemmGeom {
 };
 
 // WM x WN waves; each wave owns MT_W row tiles (32 rows) and ROWS*JC_W column tiles (32 cols).
-template <int MODE, int WM, int WN, int MT_W, int FO_T, int JC_W, int CCK, bool SWAP, bool STATS>
+template <int MODE, int WM, int WN, int MT_W, int FO_T, int JC_W, int CCK, bool SWAP, bool STATS, bool VEC>
 __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(const CgemmArgs a) {
     using G = CgemmGeom<MODE, FO_T>;
     constexpr int NT = WM * WN * 64;
     constexpr int KF = G::KF, FR = G::FR, ROWS = G::ROWS;
     constexpr int JT = 32 * JC_W * WN;
-    constexpr int PS = JT + 2;                    // patch row: columns j0-1 .. j0+JT
+    // patch row: scalar staging keeps columns j0-1 .. j0+JT; vector staging keeps the 16-byte aligned
+    // span j0-4 .. j0+JT+3 so that every row is whole float4s
+    constexpr int PS = VEC ? JT + 8 : JT + 2;
+    constexpr int COL0 = VEC ? 4 : 1;             // patch column of j0
     constexpr int NE = CCK * FR * PS;             // patch elements per K chunk
-    constexpr int NLD = (NE + NT - 1) / NT;
+    constexpr int NLD = VEC ? 1 : (NE + NT - 1) / NT;
+    constexpr int PS4 = PS / 4;
+    constexpr int NV = CCK * FR * PS4;            // float4 slots per chunk
+    constexpr int NLD4 = VEC ? (NV + NT - 1) / NT : 1;
+    static_assert(!VEC || NLD4 <= 8, "ok-mask holds 8 slots x 4 bits");
     constexpr int NCOL = ROWS * JC_W;
     constexpr int KSC = (MODE == IDV_PW) ? CCK / 2 : CCK * KF;   // MFMA k-steps per chunk
     static_assert(MODE != IDV_PW || (CCK % 2 == 0), "PW chunks are plane pairs");
@@ -96,8 +103,69 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
             for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
 
     // ---- staging: global -> registers (issued before the chunk's MFMAs) -> LDS (after them) ----------
+    // Scalar path (x1_div > 1, i.e. repeated skip connections): one element per load, address rebuilt per chunk.
+    // Vector path: one aligned float4 per slot; a slot's offset inside its chunk and its validity bits do not
+    // depend on the chunk, so the per-chunk work is one add per slot and the loads use a scalar chunk base.
     float stg[NLD];
+    f32x4 stg4[NLD4];
+    unsigned voff[NLD4];        // float offset of the slot relative to the chunk's first plane (real part)
+    unsigned okbits = 0;        // 4 validity bits per slot
+    unsigned ribits = 0;        // slot belongs to an imaginary plane
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < NLD4; ++i) {
+            const int e = tid + i * NT;
+            const int row = e / PS4, c4 = e - row * PS4;
+            const int ccl = row / FR, fr = row - ccl * FR;
+            const int fi = fbase + fr;
+            const int jv = j0 - 4 + 4 * c4;
+            const bool rowok = (e < NV) && (fi >= 0) && (fi < a.Fin);
+            unsigned bits = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (rowok && jv + q >= 0 && jv + q < a.J) bits |= 1u << q;
+            okbits |= bits << (4 * i);
+            // a slot with no valid element loads from offset 0 of its chunk (always mapped memory)
+            if (MODE == IDV_PW) {
+                voff[i] = bits ? (unsigned)(ccl * a.Jp + jv) : 0u;
+            } else {
+                if (ccl & 1) ribits |= 1u << i;
+                voff[i] = bits ? (unsigned)(((ccl >> 1) * a.Fin + fi) * a.Jp + jv) : 0u;
+            }
+        }
+    }
     auto stage_load = [&](int chunk) {
+        if (VEC) {
+            const float* base;
+            unsigned ristride;                           // distance from a real plane to its imaginary plane
+            if (MODE == IDV_PW) {
+                base = a.x0 + (size_t)chunk * CCK * a.Jp;
+                ristride = 0;
+            } else {
+                const int ci0 = chunk * (CCK / 2);       // first complex channel of the chunk
+                if (ci0 < a.C0) {
+                    base = a.x0 + (size_t)ci0 * a.Fin * a.Jp;
+                    ristride = (unsigned)a.C0 * a.Fin * a.Jp;
+                } else {
+                    base = a.x1 + (size_t)(ci0 - a.C0) * a.Fin * a.Jp1;
+                    ristride = (unsigned)a.C1 * a.Fin * a.Jp1;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NLD4; ++i) {
+                unsigned o = voff[i];
+                if (MODE == IDV_PW) {
+                    // ragged last chunk (K not a multiple of CCK): planes beyond K are read as plane 0 and masked
+                    const int e = tid + i * NT;
+                    const int ccl = e / PS4;
+                    if (chunk * CCK + ccl >= CC) o = 0u;
+                } else {
+                    o += ((ribits >> i) & 1u) ? (((okbits >> (4 * i)) & 15u) ? ristride : 0u) : 0u;
+                }
+                stg4[i] = *(const f32x4*)(base + o);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * NT;
@@ -126,7 +194,22 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
             stg[i] = *src;      // masked lanes read x0[0]: the tp == 0 guard column, zero by the layout invariant
         }
     };
-    auto stage_store = [&](float* dst) {
+    auto stage_store = [&](float* dst, int chunk) {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NLD4; ++i) {
+                const int e = tid + i * NT;
+                unsigned bits = (okbits >> (4 * i)) & 15u;
+                if (MODE == IDV_PW) {
+                    if (chunk * CCK + e / PS4 >= CC) bits = 0u;
+                }
+                f32x4 v = stg4[i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (bits >> q) & 1u ? v[q] : 0.f;
+                if (e < NV) *(f32x4*)(dst + 4 * e) = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * NT;
@@ -147,7 +230,7 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
 
     // ---- activation fragments: all patch rows one plane (PW: one plane pair) needs, one unit ahead -----
     constexpr int UNITS = (MODE == IDV_PW) ? CCK / 2 : CCK;      // pipeline units per chunk
-    const int bcol = wn * (JC_W * 32) + (lane & 31) + ((MODE == IDV_PW) ? 1 : (lane >> 5) + 1 + a.tshift);
+    const int bcol = wn * (JC_W * 32) + (lane & 31) + ((MODE == IDV_PW) ? COL0 : (lane >> 5) + COL0 + a.tshift);
     auto load_b = [&](const float* P, int u, float (&dst)[FR][JC_W]) {
 #pragma unroll
         for (int fr = 0; fr < FR; ++fr)
@@ -162,7 +245,7 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
 
     stage_load(0);
     load_a(0, a_cur);
-    stage_store(smem);
+    stage_store(smem, 0);
     // Retire the prologue's weight loads before the loop: otherwise the loop header inherits them as
     // "pending" and hipcc puts counted vmcnt waits in front of the loop's MFMAs, which in steady state
     // wait for the NEXT chunk's prefetch (a false dependency worth ~1 us per chunk).
@@ -218,7 +301,7 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
             }
         }
         if (more) {
-            stage_store(smem + ((chunk + 1) & 1) * NE);
+            stage_store(smem + ((chunk + 1) & 1) * NE, chunk + 1);
 #pragma unroll
             for (int ks = 0; ks < KSC; ++ks)
 #pragma unroll
