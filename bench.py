@@ -207,10 +207,8 @@ def main():
     loss_val = float(last)
     log(f"timed {args.steps} steps in {elapsed:.3f} s")
 
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    dt = importlib.import_module("i-dccrn-vae_amd.utils.dist_timing")
+    value, elapsed = dt.job_throughput(elapsed, float(utt_per_step * args.steps), device)
 
     # dominant kernel: group conv launches by cgemm instantiation, HIP-event durations on the launch stream
     groups = {}
@@ -243,7 +241,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": METRIC, "value": round(world * utt_per_step * args.steps / elapsed, 3), "unit": "utterances/sec",
+            "metric": METRIC, "value": round(value, 3), "unit": "utterances/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (0.1*N(0,1) clean + noise, seeded; random-init weights)",

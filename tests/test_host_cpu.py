@@ -1,0 +1,126 @@
+"""CPU: host-side logic - the C-ABI library loads and exports every symbol include/idccrn_hip.h declares
+(no compute calls), the config tables and state_dict keys, the planar view algebra, the ini reader."""
+import ctypes
+import importlib
+import os
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+NFFT, HOP, WIN = 512, 100, 400
+SKIP = [0, 1, 2, 3, 4, 5]
+
+
+def test_library_exports_every_declared_symbol(amd):
+    L = amd._lib
+    names = L.declared_symbols()
+    assert len(names) >= 24 and "idv_cconv2d_fwd" in names and "idv_clstm_fwd" in names
+    lib = L.lib()                                    # raises if the .so is missing or a symbol is absent
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.idv_abi_version() == 1
+    assert lib.idv_cconv_cck(ctypes.c_int(1)) == 2 and lib.idv_cconv_cck(ctypes.c_int(32)) == 4
+    assert lib.idv_cconv_config(ctypes.c_int(1), ctypes.c_int(64), ctypes.c_int(1), ctypes.c_int(129)) == 1141314
+    lib.idv_clstm_work_floats.restype = ctypes.c_longlong
+    assert lib.idv_clstm_work_floats(ctypes.c_int(128), ctypes.c_int(2), ctypes.c_int(641)) == 24 * 641 * 2 * 128
+
+
+def test_missing_library_fails_loudly(amd, monkeypatch):
+    L = amd._lib
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", os.path.join(ROOT, "no_such_lib.so"))
+    with pytest.raises(L.IdvError, match="no CPU fallback"):
+        L.lib()
+
+
+def test_cpu_tensors_are_rejected(amd):
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    cn = importlib.import_module("i-dccrn-vae_amd.model.causal_netconfig")
+    m = pm.DCCRN_(NFFT, HOP, cn.get_net_params(), True, "cpu", WIN, SKIP, "mask", False, None, None)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(torch.zeros(1, 6400))
+
+
+def test_net_tables():
+    cn = importlib.import_module("i-dccrn-vae_amd.model.causal_netconfig").get_net_params()
+    nc = importlib.import_module("i-dccrn-vae_amd.model.net_config").get_net_params()
+    assert cn["encoder_channels"] == [1, 32, 64, 128, 128, 256, 256]
+    assert cn["decoder_channels"] == [256, 256, 128, 128, 64, 32, 1]
+    assert cn["lstm_dim"] == [1280, 128] and cn["dense"] == [128, 1280] and cn["lstm_layer_num"] == 2
+    assert cn["encoder_paddings"] == [(2, 1)] * 6 and nc["encoder_paddings"] == [(2, 0)] * 6
+    assert {k: v for k, v in cn.items() if k != "encoder_paddings"} == {k: v for k, v in nc.items() if k != "encoder_paddings"}
+    assert cn["encoder_chw"][0] == (32, 129, 1600) and cn["decoder_chw"][-1] == (1, 257, 1601)
+
+
+def test_state_dict_keys_and_param_counts():
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    np_ = importlib.import_module("i-dccrn-vae_amd.model.causal_netconfig").get_net_params()
+    m = pm.DCCRN_(NFFT, HOP, np_, True, "cpu", WIN, SKIP, "mask", False, None, None)
+    keys = set(m.state_dict())
+    for k in ("std_DCCRN.encoders.0.conv.conv_re.weight", "std_DCCRN.encoders.5.bn.gamma_ri", "std_DCCRN.encoders.2.bn.Vri",
+              "std_DCCRN.encoders.1.prelu.weight", "std_DCCRN.lstms.0.lstm_re.weight_ih_l0", "std_DCCRN.lstms.0.lstm_im.bias_hh_l1",
+              "std_DCCRN.dense.linear_read.weight", "std_DCCRN.dense.linear_imag.bias",
+              "std_DCCRN.decoders.0.transconv.tconv_re.weight", "std_DCCRN.decoders.5.bn.running_mean_imag",
+              "std_DCCRN.linear.conv_im.bias"):
+        assert k in keys, k
+    assert len(keys) == 204
+    count = lambda mod: sum(p.numel() for p in mod.parameters())
+    assert count(m) == 9546199                                                       # SURVEY.md section 8(c) probe
+    assert m.state_dict()["std_DCCRN.decoders.0.transconv.tconv_re.weight"].shape == (512, 256, 5, 2)
+    enc = pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cpu", 128, NFFT, HOP, WIN, 5)
+    dec = pm.pvae_dccrn_decoder_skip_prepare(np_, True, "cpu", 5, 128, NFFT, HOP, WIN, "real_imag", SKIP)
+    ns = pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cpu", 128, NFFT, HOP, WIN, 2, 2)
+    assert (count(enc), count(dec), count(ns)) == (10318886, 5332909, 24880166)
+    assert enc.lstms[0].hidden_size == 384 and ns.lstms[0].hidden_size == 768
+    assert "dense.linear_read.weight" in enc.state_dict()                           # the unused dense of the reference
+    old = importlib.import_module("i-dccrn-vae_amd.model.module").DCCRN_(NFFT, HOP, importlib.import_module(
+        "i-dccrn-vae_amd.model.net_config").get_net_params(), "cpu", WIN)
+    assert "DCCRN.encoders.0.conv.conv_re.weight" in old.state_dict()
+
+
+def test_planar_views_roundtrip(amd):
+    P = amd.ops.Planar
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 4, 5, 7, 2, generator=g)
+    pl = P.from_tensor5(x, Tp=9)
+    assert pl.Jp % 4 == 0 and pl.Jp >= 3 * 9
+    assert torch.equal(pl.tensor5(), x)
+    planes = pl.planes()
+    assert planes.shape == (2, 4, 5, 3, 9)
+    assert float(planes[..., 0].abs().max()) == 0 and float(planes[..., 8:].abs().max()) == 0     # guard columns
+    assert torch.equal(planes[0, 1, 2, 1, 1:8], x[1, 1, 2, :, 0])
+    lat = P.from_tensor5(torch.randn(2, 6, 1, 5, 2, generator=g))
+    assert lat.channel_slice(2, 4).shape == (2, 5, 2, 2)
+    assert torch.equal(lat.channel_slice(2, 4), lat.tensor5()[:, 2:4, 0].permute(0, 2, 1, 3))
+
+
+def test_synth_weights_are_deterministic():
+    synth = importlib.import_module("i-dccrn-vae_amd.utils.synth")
+    a = synth.synth_tensor("encoders.0.conv.conv_re.weight", (4, 1, 5, 2), 7)
+    b = synth.synth_tensor("encoders.0.conv.conv_re.weight", (4, 1, 5, 2), 7)
+    c = synth.synth_tensor("encoders.0.conv.conv_re.weight", (4, 1, 5, 2), 8)
+    assert torch.equal(a, b) and not torch.equal(a, c) and a.dtype == torch.float32
+    v = synth.synth_tensor("bn.Vrr", (1, 8, 1, 1), 1)
+    assert float(v.min()) >= 0.5
+
+
+def test_ini_surface(tmp_path):
+    rc = importlib.import_module("i-dccrn-vae_amd.utils.read_config")
+    ini = tmp_path / "cfg.ini"
+    ini.write_text("[User]\nsaved_root = /tmp/x\nmodel_name = supervised_dccrn\n[Network]\nz_dim = 128\n"
+                   "[STFT]\nwinlen = 400\nnfft = 512\nhopfrac = 100\nfs = 16000\nmingain = -80\n"
+                   "[Training]\noptimization = adam\nlr = 3e-4\nepochs = 1000\nearly_stop_patience = 20\nsave_frequency = 10\n"
+                   "[DataFrame]\ndataset_name = d\nsuffix = wav\nnum_workers = 1\nbatch_size = 48\nshuffle = True\nsequence_len = 481\n")
+    cfg = rc.myconf()
+    cfg.read(str(ini))
+    assert cfg.getint("STFT", "winlen") == 400 and cfg.getint("STFT", "hopfrac") == 100 and cfg.getint("STFT", "nfft") == 512
+    assert cfg.getfloat("Training", "lr") == 3e-4 and cfg.getint("DataFrame", "sequence_len") == 481
+    assert "saved_root" in cfg["User"] and "Saved_Root" not in cfg["User"]            # key case is preserved
+
+
+def test_kl_annealing_schedule():
+    pl = importlib.import_module("i-dccrn-vae_amd.model.pretrain_pvaes_loss")
+    w = pl.KL_annealing(20).frange_cycle_linear(0.0, 1.0, 1, 1)
+    assert w.shape == (20,) and float(w[0]) == 0.0 and abs(float(w[10]) - 0.5) < 1e-6 and float(w[19]) <= 1.0
