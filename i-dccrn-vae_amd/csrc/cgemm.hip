@@ -11,13 +11,20 @@ int launch_vec(const CgemmArgs& a, hipStream_t st) {
     constexpr int NE = CCK * G::FR * (VEC ? JT + 8 : JT + 2);
     constexpr size_t smem = 2 * NE * sizeof(float);
     const int rows = (MODE == IDV_TCONV) ? a.Fin : a.Fout;          // TCONV tiles over input rows m
-    dim3 grid((a.J + JT - 1) / JT, (rows + FO_T - 1) / FO_T, ((a.M + 31) / 32 + WM * MT_W - 1) / (WM * MT_W));
+    CgemmArgs b = a;
+    b.jtiles = (a.J + JT - 1) / JT;
+    b.ftiles = (rows + FO_T - 1) / FO_T;
+    b.mblocks = ((a.M + 31) / 32 + WM * MT_W - 1) / (WM * MT_W);
+    const long long tiles = (long long)b.jtiles * b.ftiles;
+    const long long nblk = ((tiles + 7) / 8) * 8 * b.mblocks;
+    if (nblk > 0x7fffffffLL) return IDV_EINVAL;
+    dim3 grid((unsigned)nblk);
     auto k = cgemm_kernel<MODE, WM, WN, MT_W, FO_T, JC_W, CCK, SWAP, STATS, VEC>;
     if (smem > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return IDV_ELAUNCH;
     }
-    hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), smem, st, a);
+    hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), smem, st, b);
     return idv_launch_status();
 }
 

@@ -46,6 +46,7 @@ struct CgemmArgs {
     double* stats;        // train mode: [Cout][5] sums (r, i, rr, ii, ri) or nullptr
     int ldo;              // SWAP: row stride of out; rows are ordered (tp-1)*B + b
     int nB;               // SWAP: utterances (B)
+    int jtiles, ftiles, mblocks;   // grid decomposition (filled by the launcher)
 };
 
 template <int MODE, int FO_T>
@@ -83,10 +84,18 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // block coordinates: x = j tile, y = row (f) tile, z = m tile
-    const int j0 = blockIdx.x * JT;
-    const int ft = blockIdx.y;
-    const int mt0 = (blockIdx.z * WM + wm) * MT_W;          // first 32-row tile of this wave
+    // Block order: the MB row-tile blocks that share one input patch get consecutive slots on ONE XCD
+    // (ids equal mod 8 share an XCD under round-robin placement), so the patch is fetched from HBM once
+    // and re-read from that XCD's L2 (speed only, never correctness).
+    const int MB = a.mblocks, FTn = a.ftiles;
+    const int bid = blockIdx.x;
+    const int grp = bid / (8 * MB), rem = bid - grp * (8 * MB);
+    const int tile = grp * 8 + (rem & 7);
+    const int mblk = rem >> 3;
+    if (tile >= a.jtiles * FTn) return;                     // padding blocks of the last group
+    const int jt = tile / FTn, ft = tile - jt * FTn;
+    const int j0 = jt * JT;
+    const int mt0 = (mblk * WM + wm) * MT_W;                // first 32-row tile of this wave
     const int fo0 = ft * FO_T;                              // CONV: first output row; TCONV: first m
     const int fbase = (MODE == IDV_CONV) ? 2 * fo0 - 2 : (MODE == IDV_TCONV ? fo0 - 1 : 0);
 
@@ -257,17 +266,22 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const float* P = smem + (chunk & 1) * NE;
-        const bool more = chunk + 1 < nchunk;
-        if (more) {
-            stage_load(chunk + 1);
-            load_a(chunk + 1, a_nxt);
-        }
+        // branch-free body: the last chunk re-fetches itself (unused) instead of branching, so each unit
+        // is one scheduling region and the loads/stores below really interleave with the MFMAs
+        const int nxt = (chunk + 1 < nchunk) ? chunk + 1 : chunk;
         float b_cur[FR][JC_W], b_nxt[FR][JC_W];
         load_b(P, 0, b_cur);
 #pragma unroll
         for (int u = 0; u < UNITS; ++u) {
             if (u + 1 < UNITS) load_b(P, u + 1, b_nxt);
             __builtin_amdgcn_sched_barrier(0);        // keep the next unit's LDS reads ahead of this unit's MFMAs
+            // the next chunk's global loads ride in the shadow of unit 0's MFMAs, its LDS writes in the
+            // shadow of the last unit's (the other LDS buffer is idle: every wave passed the last barrier)
+            if (u == 0) {
+                stage_load(nxt);
+                load_a(nxt, a_nxt);
+            }
+            if (u == UNITS - 1) stage_store(smem + ((chunk + 1) & 1) * NE, nxt);
 #pragma unroll
             for (int kf = 0; kf < KF; ++kf) {
                 const int ks = (MODE == IDV_PW) ? u : u * KF + kf;
@@ -300,13 +314,10 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
                     for (int jc = 0; jc < JC_W; ++jc) b_cur[fr][jc] = b_nxt[fr][jc];
             }
         }
-        if (more) {
-            stage_store(smem + ((chunk + 1) & 1) * NE, chunk + 1);
 #pragma unroll
-            for (int ks = 0; ks < KSC; ++ks)
+        for (int ks = 0; ks < KSC; ++ks)
 #pragma unroll
-                for (int i = 0; i < MT_W; ++i) a_cur[ks][i] = a_nxt[ks][i];
-        }
+            for (int i = 0; i < MT_W; ++i) a_cur[ks][i] = a_nxt[ks][i];
         __syncthreads();
     }
 

@@ -59,23 +59,35 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(const RecArgs a) {
     }
     __syncthreads();
 
+    // gate pre-activations of step t+1 are fetched while step t computes (they do not depend on h)
+    f32x4 gcur[WREG ? 2 : 1][4], gnxt[WREG ? 2 : 1][4];
+    auto load_g = [&](int t, f32x4 (&dst)[WREG ? 2 : 1][4]) {
+        const size_t rb = (size_t)t * a.B + b0;
+#pragma unroll
+        for (int u = 0; u < (WREG ? 2 : 1); ++u) {
+            const int ub = wave + 4 * u;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (b0 + rq * 4 + r < a.B) ? rq * 4 + r : 0;      // clamp: rows beyond B are never stored
+                    dst[u][gg][r] = g[(rb + row) * a.ldg + (ub * 4 + gg) * 16 + col];
+                }
+        }
+    };
+    if (WREG) load_g(0, gcur);
+
     for (int t = 0; t < a.T; ++t) {
         const float* hc = hT + (t & 1) * H * 16;
         float* hn = hT + ((t + 1) & 1) * H * 16;
         const size_t rowbase = (size_t)t * a.B + b0;
         if (WREG) {
+            if (t + 1 < a.T) load_g(t + 1, gnxt);
             f32x4 acc[2][4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ub = wave + 4 * u;
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int gg = 0; gg < 4; ++gg)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rq * 4 + r;
-                        acc[u][gg][r] = (b0 + row < a.B) ? g[(rowbase + row) * a.ldg + (ub * 4 + gg) * 16 + col] : 0.f;
-                    }
-            }
+                for (int gg = 0; gg < 4; ++gg) acc[u][gg] = gcur[u][gg];
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) {
                 const float av = hc[64 * kk + lane];
@@ -101,6 +113,10 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(const RecArgs a) {
                 }
                 *(f32x4*)&hn[unit * 16 + rq * 4] = hv;
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) gcur[u][gg] = gnxt[u][gg];
         } else {
             for (int ub = wave; ub < NUB; ub += 4) {
                 f32x4 acc[4];
