@@ -156,6 +156,97 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(const RecArgs a) {
     }
 }
 
+// One time step for hidden sizes whose W_hh does not fit a CU's registers (H = 384, 768 of the VAE encoders):
+// the 4H gate columns are split over workgroups (32 units x 4 gates = 128 columns each), every workgroup takes
+// 16 sequences of one run, its 4 waves split K, partial gate tiles are reduced through LDS and waves 0/1 do
+// the cell update for one 16-unit block each.  h_{t-1} is read from the output of the previous launch
+// (kernel boundary = the only synchronisation), c lives in global memory.  The 2*T launches per LSTM are
+// queued back to back on the caller's stream; W_hh (2.4 / 9.4 MB per set) stays L2 resident across them.
+struct StepArgs {
+    RecArgs r;
+    float* cstate;   // [4 runs][B][H]
+    int t;
+};
+
+__global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const RecArgs& a = sa.r;
+    const int H = a.H, t = sa.t;
+    float* hT = sm;                       // [H][16]
+    float* red = sm + (size_t)H * 16;     // [4 waves][8 tiles][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cs = blockIdx.x, b0 = blockIdx.y * 16, run = blockIdx.z, z = run >> 1, s = run & 1;
+    const int col = lane & 15, rq = lane >> 4;
+    const int KK = H / 4;
+    const float* g = a.g + z * a.g_run_z + s * a.g_run_s;
+    const float* whh = a.whh + (size_t)s * 4 * H * H;
+    float* hout = a.hout + (size_t)run * a.T * a.B * H;
+    float* cst = sa.cstate + (size_t)run * a.B * H;
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] = 0.f;
+
+    if (t > 0) {
+        // h_{t-1}[16 seqs][H] -> LDS transposed [k][seq]
+        const float* hp = hout + ((size_t)(t - 1) * a.B + b0) * H;
+        for (int e = tid; e < 16 * (H / 4); e += 256) {
+            const int row = e / (H / 4), k4 = e - row * (H / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b0 + row < a.B) v = *(const f32x4*)(hp + (size_t)row * H + 4 * k4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hT[(4 * k4 + q) * 16 + row] = v[q];
+        }
+        __syncthreads();
+        const int kw = KK / 4;             // k-steps per wave
+        const float* wt = whh + ((size_t)(cs * 8) * KK + wave * kw) * 64 + lane;
+        const float* hk = hT + (size_t)wave * kw * 64 + lane;
+#pragma unroll 4
+        for (int kk = 0; kk < kw; ++kk) {
+            const float av = hk[64 * kk];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wt[((size_t)q * KK + kk) * 64], acc[q], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *(f32x4*)&red[((wave * 8 + q) * 64 + lane) * 4] = acc[q];
+    __syncthreads();
+    if (wave < 2) {
+        const int ub = cs * 2 + wave;                  // 16-unit block finished by this wave
+        const int unit = ub * 16 + col;
+        const size_t rowbase = (size_t)t * a.B + b0;
+        f32x4 gate[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x4 p = *(const f32x4*)&red[((w * 8 + wave * 4 + gg) * 64 + lane) * 4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += p[r];
+            }
+            gate[gg] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rq * 4 + r;
+            if (b0 + row >= a.B) continue;
+            const float* gp = g + (rowbase + row) * a.ldg + ub * 64 + col;
+            const float ig = sigmoidf_(gate[0][r] + gp[0]), fg = sigmoidf_(gate[1][r] + gp[16]);
+            const float gv = tanhf(gate[2][r] + gp[32]), og = sigmoidf_(gate[3][r] + gp[48]);
+            const size_t ci = (size_t)(b0 + row) * H + unit;
+            const float cprev = (t > 0) ? cst[ci] : 0.f;
+            const float cn = fg * cprev + ig * gv;
+            cst[ci] = cn;
+            hout[(rowbase + row) * H + unit] = og * tanhf(cn);
+        }
+    }
+}
+
 // G1[run][pos][4H] = X[run][pos][H] * W^T + bias   (layer-1 input projection; X row-major)
 // block: 32 positions x 4H columns of one run; wave w owns column tiles w, w+4, ...
 template <int NCT>   // column tiles (32) per wave = 4H / 128
@@ -294,11 +385,21 @@ __global__ void zero_tail_kernel(float* __restrict__ act, int planes, int B, int
     }
 }
 
-int launch_rec(const RecArgs& ra, hipStream_t st) {
+int launch_rec(const RecArgs& ra, float* cstate, hipStream_t st) {
     dim3 grid((ra.B + 15) / 16, 4);
     if (ra.H == 128) {
         const size_t smem = (size_t)2 * 128 * 16 * sizeof(float);
         hipLaunchKernelGGL(lstm_rec_kernel<true>, grid, dim3(256), smem, st, ra);
+    } else if (ra.H % 32 == 0 && cstate) {
+        const size_t smem = ((size_t)ra.H * 16 + 4 * 8 * 64 * 4) * sizeof(float);
+        if (smem > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)lstm_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return IDV_ELAUNCH;
+        dim3 sgrid(ra.H / 32, (ra.B + 15) / 16, 4);
+        for (int t = 0; t < ra.T; ++t) {
+            StepArgs sa{ra, cstate, t};
+            hipLaunchKernelGGL(lstm_step_kernel, sgrid, dim3(256), smem, st, sa);
+        }
     } else {
         const size_t smem = (size_t)3 * ra.H * 16 * sizeof(float);
         if (smem > 64 * 1024 &&
@@ -311,7 +412,7 @@ int launch_rec(const RecArgs& ra, hipStream_t st) {
 
 }  // namespace
 
-extern "C" long long idv_clstm_work_floats(int H, int B, int T) { return 24LL * T * B * H; }
+extern "C" long long idv_clstm_work_floats(int H, int B, int T) { return 24LL * T * B * H + 4LL * B * H; }
 
 extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
                              const float* wih1, const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp,
@@ -324,6 +425,7 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     float* G = work;                       // [2][TB][8H]  then  [4][TB][4H]
     float* h0 = work + 16 * TB * H;        // [4][TB][H]
     float* h1 = h0 + 4 * TB * H;
+    float* cstate = h1 + 4 * TB * H;       // [4][B][H], used by the per-step kernel only
     int rc;
     // layer 0 input projection: both weight sets at once (M = 8H), one call per input part z
     for (int z = 0; z < 2; ++z) {
@@ -332,7 +434,7 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
         if (rc) return rc;
     }
     RecArgs r0{G, TB * 8 * H, 4LL * H, 8 * H, whh0, h0, H, B, T};
-    if ((rc = launch_rec(r0, st))) return rc;
+    if ((rc = launch_rec(r0, cstate, st))) return rc;
     // layer 1 input projection from h0 (row-major), per run
     const int KS = ((H + 7) / 8) * 4;
     dim3 ggrid((unsigned)((TB + 31) / 32), 4);
@@ -348,7 +450,7 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     if ((rc = idv_launch_status())) return rc;
     // G1 is [run][TB][4H] with run = 2z + s
     RecArgs r1{G, 2 * TB * 4 * H, TB * 4 * H, 4 * H, whh1, h1, H, B, T};
-    if ((rc = launch_rec(r1, st))) return rc;
+    if ((rc = launch_rec(r1, cstate, st))) return rc;
     hipLaunchKernelGGL(lstm_combine_kernel, dim3((T + 31) / 32, (H + 31) / 32, B), dim3(256), 0, st, h1, H, B, T, Tp, Jp, out);
     const long long ntail = 2LL * H * B * (Tp - 1 - T);
     if (ntail > 0)

@@ -13,6 +13,16 @@ from ._lib import call, p, i, f, d, ll, stream_ptr
 SLACK = 256
 
 
+def bucket(n: int) -> int:
+    """Round a buffer length up to one of 8 size classes per octave (<= 12.5 % slack).  Layer outputs of
+    slightly different sizes then land in the same class, so the caching allocator re-uses whole blocks
+    instead of splitting multi-GB ones and calling hipMalloc again on the next step."""
+    if n <= 4096:
+        return n
+    step = 1 << (n.bit_length() - 4)
+    return (n + step - 1) // step * step
+
+
 class Planar:
     """A planar-J activation  act[2][C][F][Jp]  (see include/idccrn_hip.h).
 
@@ -32,7 +42,7 @@ class Planar:
     @classmethod
     def empty(cls, C, F, B, T, Tp, device, zero=False):
         Jp = cls.jp_for(B, Tp)
-        n = 2 * C * F * Jp + 2 * SLACK
+        n = bucket(2 * C * F * Jp + 2 * SLACK)
         buf = (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=device)
         return cls(buf, C, F, B, T, Tp, Jp)
 
@@ -180,7 +190,7 @@ def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
     K = x.C * x.F
     out = Planar.empty(H, 1, x.B, x.T, x.Tp, x.buf.device)
     nwork = L.lib().idv_clstm_work_floats(i(H), i(x.B), i(x.T))
-    work = torch.empty(nwork, dtype=torch.float32, device=x.buf.device)
+    work = torch.empty(bucket(int(nwork)), dtype=torch.float32, device=x.buf.device)
     call("idv_clstm_fwd", x.ptr(), i(K), p(packed0[0]), p(packed0[1]), p(packed0[2]), p(packed1[0]), p(packed1[1]),
          p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), stream_ptr())
     return out
