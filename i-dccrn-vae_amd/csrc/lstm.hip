@@ -190,6 +190,21 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs sa) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[q][r] = 0.f;
 
+    // inputs of the cell update do not depend on the MFMA loop: fetch them first (waves 0/1 finish one
+    // 16-unit block each), so their latency hides behind the h staging and the contraction
+    float gpre[4][4], cpre[4];
+    if (wave < 2) {
+        const int ubp = cs * 2 + wave;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (b0 + rq * 4 + r < a.B) ? rq * 4 + r : 0;
+            const float* gp = g + ((size_t)t * a.B + b0 + row) * a.ldg + ubp * 64 + col;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) gpre[gg][r] = gp[16 * gg];
+            cpre[r] = (t > 0) ? cst[(size_t)(b0 + row) * H + ubp * 16 + col] : 0.f;
+        }
+    }
+
     if (t > 0) {
         // h_{t-1}[16 seqs][H] -> LDS transposed [k][seq]
         const float* hp = hout + ((size_t)(t - 1) * a.B + b0) * H;
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs sa) {
         const int kw = KK / 4;             // k-steps per wave
         const float* wt = whh + ((size_t)(cs * 8) * KK + wave * kw) * 64 + lane;
         const float* hk = hT + (size_t)wave * kw * 64 + lane;
-#pragma unroll 4
+#pragma unroll 8
         for (int kk = 0; kk < kw; ++kk) {
             const float av = hk[64 * kk];
 #pragma unroll
@@ -235,12 +250,10 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs sa) {
         for (int r = 0; r < 4; ++r) {
             const int row = rq * 4 + r;
             if (b0 + row >= a.B) continue;
-            const float* gp = g + (rowbase + row) * a.ldg + ub * 64 + col;
-            const float ig = sigmoidf_(gate[0][r] + gp[0]), fg = sigmoidf_(gate[1][r] + gp[16]);
-            const float gv = tanhf(gate[2][r] + gp[32]), og = sigmoidf_(gate[3][r] + gp[48]);
+            const float ig = sigmoidf_(gate[0][r] + gpre[0][r]), fg = sigmoidf_(gate[1][r] + gpre[1][r]);
+            const float gv = tanhf(gate[2][r] + gpre[2][r]), og = sigmoidf_(gate[3][r] + gpre[3][r]);
             const size_t ci = (size_t)(b0 + row) * H + unit;
-            const float cprev = (t > 0) ? cst[ci] : 0.f;
-            const float cn = fg * cprev + ig * gv;
+            const float cn = fg * cpre[r] + ig * gv;
             cst[ci] = cn;
             hout[(rowbase + row) * H + unit] = og * tanhf(cn);
         }
@@ -372,6 +385,30 @@ __global__ __launch_bounds__(256) void lstm_combine_kernel(const float* __restri
         }
 }
 
+// h[run][t*B + b][u] -> hp[run][u][b*Tp + t + 1] (planar, one plane set per run) so that the layer-1 input
+// projection can run on the tuned PW contraction kernel; guard columns zeroed.
+__global__ __launch_bounds__(256) void lstm_to_planar_kernel(const float* __restrict__ h, int H, int B, int T, int Tp, int Jp,
+                                                             float* __restrict__ hp) {
+    __shared__ float tr[32][33];
+    const int b = blockIdx.z % B, run = blockIdx.z / B, t0 = blockIdx.x * 32, u0 = blockIdx.y * 32;
+    const size_t TB = (size_t)T * B;
+    const float* src = h + (size_t)run * TB * H;
+    float* dst = hp + (size_t)run * H * Jp;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, u = u0 + tx;
+        tr[i][tx] = (t < T && u < H) ? src[((size_t)t * B + b) * H + u] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + tx, u = u0 + i;
+        if (t < T && u < H) dst[(size_t)u * Jp + (size_t)b * Tp + t + 1] = tr[tx][i];
+    }
+    if (blockIdx.x == 0 && tx == 0)
+        for (int i = ty; i < 32; i += 8)
+            if (u0 + i < H) dst[(size_t)(u0 + i) * Jp + (size_t)b * Tp] = 0.f;
+}
+
 __global__ void zero_tail_kernel(float* __restrict__ act, int planes, int B, int T, int Tp, int Jp) {
     // columns tp in (T, Tp) of every utterance
     const int tail = Tp - 1 - T;
@@ -412,7 +449,9 @@ int launch_rec(const RecArgs& ra, float* cstate, hipStream_t st) {
 
 }  // namespace
 
-extern "C" long long idv_clstm_work_floats(int H, int B, int T) { return 24LL * T * B * H + 4LL * B * H; }
+extern "C" long long idv_clstm_work_floats(int H, int B, int T, int Jp) {
+    return 24LL * T * B * H + 4LL * B * H + 4LL * H * Jp;
+}
 
 extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
                              const float* wih1, const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp,
@@ -440,6 +479,17 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     dim3 ggrid((unsigned)((TB + 31) / 32), 4);
     if (H == 128) {
         hipLaunchKernelGGL(gemm_rm_kernel<4>, ggrid, dim3(256), 0, st, h0, wih1, bih1, G, H, TB, KS);
+    } else if (H % 32 == 0) {
+        // transpose h0 to planar and use the PW contraction: rows of weight set s start at tile s*(4H/32)
+        float* hp = cstate + 4LL * B * H;              // [4 runs][H][Jp]
+        hipLaunchKernelGGL(lstm_to_planar_kernel, dim3((T + 31) / 32, (H + 31) / 32, 4 * B), dim3(256), 0, st, h0, H, B, T, Tp, Jp, hp);
+        if ((rc = idv_launch_status())) return rc;
+        for (int run = 0; run < 4; ++run) {
+            const int sset = run & 1;
+            rc = idv_pw_gemm(hp + (size_t)run * H * Jp, H, wih1 + (size_t)sset * (4 * H / 32) * KS * 64, bih1 + sset * 4 * H, nullptr,
+                             G + (size_t)run * TB * 4 * H, 4 * H, B, Tp, Jp, T, 1, 4 * H, stream);
+            if (rc) return rc;
+        }
     } else {
         const size_t smem = (size_t)32 * (H + 1) * sizeof(float);
         if (smem > 64 * 1024 &&

@@ -189,7 +189,7 @@ def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
     """ComplexLSTM forward: x planar with C*F = K feature planes per part -> planar [2][H][Jp] (F = 1)."""
     K = x.C * x.F
     out = Planar.empty(H, 1, x.B, x.T, x.Tp, x.buf.device)
-    nwork = L.lib().idv_clstm_work_floats(i(H), i(x.B), i(x.T))
+    nwork = L.lib().idv_clstm_work_floats(i(H), i(x.B), i(x.T), i(x.Jp))
     work = torch.empty(bucket(int(nwork)), dtype=torch.float32, device=x.buf.device)
     call("idv_clstm_fwd", x.ptr(), i(K), p(packed0[0]), p(packed0[1]), p(packed0[2]), p(packed1[0]), p(packed1[1]),
          p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), stream_ptr())

@@ -119,8 +119,8 @@ int idv_planar_to_complex(const float* act, float* out_c, int F, int B, int T, i
 
 /* ComplexLSTM.forward (complex_progress.py:50-74): four 2-layer LSTM passes, real = rr - ii,
  * imag = ir + ri.  x: planar [2][K][Jp]; out: planar [2][H][Jp].  wihN / bihN: idv_pack_lstm_ih of layer
- * N, whhN: idv_pack_lstm_hh of layer N.  work: idv_clstm_work_floats(H, B, T) floats. */
-long long idv_clstm_work_floats(int H, int B, int T);   /* 24*T*B*H + 4*B*H */
+ * N, whhN: idv_pack_lstm_hh of layer N.  work: idv_clstm_work_floats(H, B, T, Jp) floats. */
+long long idv_clstm_work_floats(int H, int B, int T, int Jp);   /* 24*T*B*H + 4*B*H + 4*H*Jp */
 int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0, const float* wih1,
                   const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp, float* work, float* out,
                   void* stream);
