@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--workload", default="dccrn_cl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("IDV_PRECISION", "fp32"), choices=["fp32", "bf16x3"],
+                    help="conv contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
 
     import torch
@@ -180,6 +182,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     ops = importlib.import_module("i-dccrn-vae_amd").ops
+    ops.set_precision(args.precision)
     torch.set_grad_enabled(False)
     step, utt_per_step, cfg = build_workload(args.workload, args.batch, device, rank)
 
@@ -223,13 +226,15 @@ def main():
         macs, secs, n = groups[dom]
         tot_macs = sum(g[0] for g in groups.values())
         tot_secs = sum(g[1] for g in groups.values())
-        d = str(dom)
+        d = str(abs(dom))
         mode = "TCONV" if len(d) == 7 else "CONV"
         t = d[-6:]
+        kname = (f"cgemm_kernel<{mode}, WM={t[0]}, WN={t[1]}, MT_W={t[2]}, FO_T={t[3]}, JC_W={t[4]}, CCK={t[5]}>" if dom > 0
+                 else f"cgemm_bf16_kernel<{mode}> (split-bf16 variant of layer class {d})")
         roofline = {
             "bound": "mfma", "achieved": round(2 * macs / secs / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(2 * macs / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": f"cgemm_kernel<{mode}, WM={t[0]}, WN={t[1]}, MT_W={t[2]}, FO_T={t[3]}, JC_W={t[4]}, CCK={t[5]}>",
+            "kernel": kname,
             "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
             "algorithmic_gflop_per_launch": round(2 * macs / n / 1e9, 3),
             "all_conv_launches": {"achieved": round(2 * tot_macs / tot_secs / 1e12, 3),
@@ -244,7 +249,8 @@ def main():
             "metric": METRIC, "value": round(value, 3), "unit": "utterances/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (0.1*N(0,1) clean + noise, seeded; random-init weights)",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-fp32 operands on bf16 MFMA, fp32 accumulate)", "data": "synthetic (0.1*N(0,1) clean + noise, seeded; random-init weights)",
             "config": dict(cfg, utterance="4 s @ 16 kHz (64000 samples, 641 frames)", parallelism=f"replicas x{world}",
                            loss=loss_val),
             "roofline": roofline,

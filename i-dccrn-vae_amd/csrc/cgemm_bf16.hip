@@ -1,0 +1,396 @@
+// Split-precision variant of the complex conv / transposed-conv contraction: every fp32 operand is
+// split as x = hi + lo (two bf16), and  w*x ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi  is accumulated in fp32 on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate; 3 MFMAs per 16-deep k block, dropped term 2^-16 relative).
+// Same math, block-weight formulation, planar-J global layout, epilogue and C-ABI as cgemm.hpp; what changes
+// is the K order inside the workgroup: bf16 MFMA wants 8 consecutive k per lane, so the LDS patch is
+// channels-last ([freq row][column][16 planar channels], hi and lo images) and the 16-deep k block of one
+// MFMA is 16 planar channels of ONE (freq tap, time tap).  Staging transposes on the fly: a thread loads
+// 8 channel planes x 4 columns (8 aligned float4), converts, and writes 4 + 4 ds_write_b128.
+// Weights: pre-split bf16 fragments [row tile][chunk][tap][hi|lo][lane] x 16 B, streamed from L2 through a
+// 5-tap register ring (4 taps of prefetch distance).
+#include "cgemm.hpp"
+#include "../../include/idccrn_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
+
+template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS>
+__global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_bf16_kernel(const CgemmArgs a) {
+    using G = CgemmGeom<MODE, FO_T>;
+    constexpr int NT = WM * WN * 64;
+    constexpr int KF = 5, FR = G::FR, ROWS = G::ROWS;
+    constexpr int JT = 32 * JC_W * WN;
+    constexpr int PS = JT + 8;                       // columns j0-4 .. j0+JT+3
+    constexpr int PS4 = PS / 4;
+    constexpr int NCOL = ROWS * JC_W;
+    constexpr int IMG = FR * PS * 16;                // bf16 elements of one image (hi or lo)
+    constexpr int BUF = 2 * IMG;                     // hi + lo
+    constexpr int NTASK = FR * PS4 * 2;              // (row, 4-column group, channel octet)
+    constexpr int NLD = (NTASK + NT - 1) / NT;
+    constexpr int RING = 5;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int MB = a.mblocks, FTn = a.ftiles;
+    const int bid = blockIdx.x;
+    const int grp = bid / (8 * MB), rem = bid - grp * (8 * MB);
+    const int tile = grp * 8 + (rem & 7);
+    const int mblk = rem >> 3;
+    if (tile >= a.jtiles * FTn) return;
+    const int jt = tile / FTn, ft = tile - jt * FTn;
+    const int j0 = jt * JT;
+    const int mt0 = mblk * WM + wm;                          // this wave's 32-row tile
+    const int fo0 = ft * FO_T;
+    const int fbase = (MODE == IDV_CONV) ? 2 * fo0 - 2 : fo0 - 1;
+
+    const int CC = 2 * (a.C0 + a.C1);
+    const int nchunk = CC / 16;
+
+    f32x16 acc[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    // ---- staging ------------------------------------------------------------------------------------
+    f32x4 stg[NLD][8];
+    unsigned voff[NLD];
+    unsigned okbits = 0;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + i * NT;
+        const int oct = e & 1, rest = e >> 1;
+        const int fr = rest / PS4, c4 = rest - fr * PS4;
+        const int fi = fbase + fr;
+        const int jv = j0 - 4 + 4 * c4;
+        const bool rowok = (e < NTASK) && (fi >= 0) && (fi < a.Fin);
+        unsigned bits = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (rowok && jv + q >= 0 && jv + q < a.J) bits |= 1u << q;
+        okbits |= bits << (4 * i);
+        voff[i] = bits ? (unsigned)((4 * oct * a.Fin + fi) * a.Jp + jv) : 0u;
+    }
+    auto stage_load = [&](int chunk) {
+        const int ci0 = chunk * 8;
+        const float* base;
+        unsigned ristride, chstride;
+        if (ci0 < a.C0) {
+            base = a.x0 + (size_t)ci0 * a.Fin * a.Jp;
+            ristride = (unsigned)a.C0 * a.Fin * a.Jp;
+            chstride = (unsigned)a.Fin * a.Jp;
+        } else {
+            base = a.x1 + (size_t)(ci0 - a.C0) * a.Fin * a.Jp1;
+            ristride = (unsigned)a.C1 * a.Fin * a.Jp1;
+            chstride = (unsigned)a.Fin * a.Jp1;
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const bool any = ((okbits >> (4 * i)) & 15u) != 0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                // plane p of the octet: complex channel p>>1, part p&1
+                const unsigned o = any ? voff[i] + (p >> 1) * chstride + (p & 1) * ristride : 0u;
+                stg[i][p] = *(const f32x4*)(base + o);
+            }
+        }
+    };
+    auto stage_store = [&](unsigned short* dst) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * NT;
+            const int oct = e & 1, rest = e >> 1;
+            const unsigned bits = (okbits >> (4 * i)) & 15u;
+            if (e < NTASK) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[8];
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) v[p] = ((bits >> q) & 1u) ? stg[i][p][q] : 0.f;
+                    uint4 hi, lo;
+                    float r[8];
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) r[p] = v[p] - bf16_round(v[p]);
+                    hi.x = pack_bf16(v[0], v[1]); hi.y = pack_bf16(v[2], v[3]);
+                    hi.z = pack_bf16(v[4], v[5]); hi.w = pack_bf16(v[6], v[7]);
+                    lo.x = pack_bf16(r[0], r[1]); lo.y = pack_bf16(r[2], r[3]);
+                    lo.z = pack_bf16(r[4], r[5]); lo.w = pack_bf16(r[6], r[7]);
+                    // (row, column) index = rest*4 + q because rest = fr*PS4 + c4 and PS = 4*PS4
+                    unsigned short* d = dst + ((size_t)(rest * 4 + q) * 16 + 8 * oct);
+                    *(uint4*)d = hi;
+                    *(uint4*)(d + IMG) = lo;
+                }
+            }
+        }
+    };
+
+    // ---- weight ring ---------------------------------------------------------------------------------
+    const int NTAP = nchunk * 10;
+    const uint4* wstream = (const uint4*)a.wfrag + (size_t)mt0 * NTAP * 128 + lane;
+    uint4 a_hi[RING], a_lo[RING];
+    auto load_a = [&](int g, int slot) {
+        const int gg = g < NTAP ? g : NTAP - 1;            // past the end: harmless re-read
+        a_hi[slot] = wstream[(size_t)gg * 128];
+        a_lo[slot] = wstream[(size_t)gg * 128 + 64];
+    };
+
+    // ---- activation fragments ------------------------------------------------------------------------
+    const int half = lane >> 5, l31 = lane & 31;
+    int cbase[2];                                           // column of this lane for time tap kt
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int toff = (MODE == IDV_CONV) ? kt + a.tshift : -kt;
+        cbase[kt] = wn * (JC_W * 32) + l31 + 4 + toff;
+    }
+
+    stage_load(0);
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) load_a(s, s);
+    stage_store(smem16);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const unsigned short* P = smem16 + (chunk & 1) * BUF;
+        const int nxt = (chunk + 1 < nchunk) ? chunk + 1 : chunk;
+#pragma unroll
+        for (int tap = 0; tap < 10; ++tap) {
+            const int kf = tap >> 1, kt = tap & 1;
+            load_a(chunk * 10 + tap + RING - 1, (tap + RING - 1) % RING);
+            if (tap == 0) stage_load(nxt);
+            if (tap == 8) stage_store(smem16 + ((chunk + 1) & 1) * BUF);
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi[tap % RING]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, a_lo[tap % RING]);
+#pragma unroll
+            for (int rt = 0; rt < ROWS; ++rt) {
+                int fr;
+                if (MODE == IDV_CONV) {
+                    fr = 2 * rt + kf;
+                } else {
+                    if ((rt & 1) != (kf & 1)) continue;
+                    fr = (rt >> 1) + 2 - (kf >> 1);
+                }
+#pragma unroll
+                for (int jc = 0; jc < JC_W; ++jc) {
+                    const unsigned short* src = P + ((size_t)(fr * PS + cbase[kt] + jc * 32) * 16 + 8 * half);
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4*)src);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(src + IMG));
+                    f32x16 c = acc[rt * JC_W + jc];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                    acc[rt * JC_W + jc] = c;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue (as cgemm.hpp, !SWAP)
+    const float slope = a.slope ? *a.slope : 1.0f;
+    const bool has_act = a.slope != nullptr;
+    {
+        const int mt = mt0;
+        float bia[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bia[r] = a.bias[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+        float st[STATS ? 8 : 1][5];
+        if (STATS) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int s = 0; s < 5; ++s) st[q][s] = 0.f;
+        }
+#pragma unroll
+        for (int jc = 0; jc < JC_W; ++jc) {
+            const int j = j0 + wn * (JC_W * 32) + jc * 32 + l31;
+            const int tp = j % a.Tp;
+            const bool keep = (tp >= 1) && (tp <= a.t_valid);
+            const bool inb = j < a.J;
+#pragma unroll
+            for (int rt = 0; rt < ROWS; ++rt) {
+                const int fo = (MODE == IDV_TCONV) ? 2 * (fo0 + (rt >> 1)) + (rt & 1) : fo0 + rt;
+                if (fo >= a.Fout) continue;
+                const f32x16 v = acc[rt * JC_W + jc];
+                float y[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float t = v[r] + bia[r];
+                    if (has_act) t = t >= 0.f ? t : slope * t;
+                    y[r] = keep ? t : 0.f;
+                    if (m < a.M && inb) {
+                        const int plane = (m & 1) * a.Cout + (m >> 1);
+                        a.out[((size_t)plane * a.Fout + fo) * a.Jp + j] = y[r];
+                    }
+                }
+                if (STATS) {
+                    if (inb && keep) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float yr = y[2 * q], yi = y[2 * q + 1];
+                            st[q][0] += yr; st[q][1] += yi; st[q][2] += yr * yr; st[q][3] += yi * yi; st[q][4] += yr * yi;
+                        }
+                    }
+                }
+            }
+        }
+        if (STATS) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int m = mt * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * half;
+#pragma unroll
+                for (int s = 0; s < 5; ++s) {
+                    float t = st[q][s];
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                    if (l31 == 0 && m < a.M) atomicAdd(&a.stats[(size_t)(m >> 1) * 5 + s], (double)t);
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS>
+int launch_bf16(const CgemmArgs& a, hipStream_t st) {
+    using G = CgemmGeom<MODE, FO_T>;
+    constexpr int JT = 32 * JC_W * WN;
+    constexpr size_t smem = (size_t)2 * 2 * G::FR * (JT + 8) * 16 * sizeof(unsigned short);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    const int rows = (MODE == IDV_TCONV) ? a.Fin : a.Fout;
+    CgemmArgs b = a;
+    b.jtiles = (a.J + JT - 1) / JT;
+    b.ftiles = (rows + FO_T - 1) / FO_T;
+    b.mblocks = ((a.M + 31) / 32 + WM - 1) / WM;
+    const long long tiles = (long long)b.jtiles * b.ftiles;
+    const long long nblk = ((tiles + 7) / 8) * 8 * b.mblocks;
+    if (nblk > 0x7fffffffLL) return IDV_EINVAL;
+    auto k = cgemm_bf16_kernel<MODE, WM, WN, FO_T, JC_W, STATS>;
+    if (smem > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return IDV_ELAUNCH;
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(WM * WN * 64), smem, st, b);
+    return idv_launch_status();
+}
+
+inline int waste(int n, int t) { return ((n + t - 1) / t) * t - n; }
+
+// W'(m, cc, kf, kt) of the block matrix [[Wr,-Wi],[Wi,Wr]] with the optional BN fold (same as pack.hip)
+__device__ float wprime(const float* w_re, const float* w_im, const float* fold, int Cout, int Cin_total, int Cin_used,
+                        int transposed, int m, int cc, int kf, int kt) {
+    const int co = m >> 1, ro = m & 1, ci = cc >> 1, ri = cc & 1;
+    if (co >= Cout || ci >= Cin_used) return 0.f;
+    const size_t off = transposed ? (((size_t)ci * Cout + co) * 5 + kf) * 2 + kt
+                                  : (((size_t)co * Cin_total + ci) * 5 + kf) * 2 + kt;
+    const float wr = w_re[off], wi = w_im[off];
+    const float top = ri == 0 ? wr : -wi, bot = ri == 0 ? wi : wr;
+    if (fold) {
+        const float* z = fold + (size_t)co * 6;
+        return ro == 0 ? z[0] * top + z[1] * bot : z[2] * top + z[3] * bot;
+    }
+    return ro == 0 ? top : bot;
+}
+
+// out[mt][g = chunk*10 + tap][split][lane] (uint4 = 8 bf16): lane l holds row mt*32 + (l&31), channels
+// 16*chunk + 8*(l>>5) + 0..7 of tap (kf = tap>>1, kt = tap&1)
+__global__ void pack_cconv_bf16_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im,
+                                       const float* __restrict__ fold, int Cout, int Cin_total, int Cin_used,
+                                       int transposed, int nchunk, int Mtiles, uint4* __restrict__ out) {
+    const long long n = (long long)Mtiles * nchunk * 10 * 2 * 64;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        long long t = idx >> 6;
+        const int split = (int)(t & 1); t >>= 1;
+        const int tap = (int)(t % 10); t /= 10;
+        const int chunk = (int)(t % nchunk);
+        const int mt = (int)(t / nchunk);
+        const int m = mt * 32 + (lane & 31);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = wprime(w_re, w_im, fold, Cout, Cin_total, Cin_used, transposed, m,
+                                   16 * chunk + 8 * (lane >> 5) + j, tap >> 1, tap & 1);
+            v[j] = split == 0 ? w : w - bf16_round(w);
+        }
+        uint4 o;
+        o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
+        out[idx] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" long long idv_cconv_bf16_wfrag_bytes(int Cout, int cin_used) {
+    const long long mt = ((2LL * Cout + 127) / 128) * 4;
+    const long long nchunk = (2LL * cin_used + 15) / 16;
+    return mt * nchunk * 10 * 2 * 64 * 16;
+}
+
+extern "C" int idv_cconv_bf16_supported(int transposed, int C0, int C1, int x1_div, int Cout) {
+    if (C0 % 8 || C1 % 8 || x1_div != 1) return 0;
+    if (2 * Cout < 64) return 0;
+    (void)transposed;
+    return 1;
+}
+
+extern "C" int idv_pack_cconv_bf16(const float* w_re, const float* w_im, const float* fold, int Cout, int Cin_total,
+                                   int Cin_used, int transposed, void* wfrag, void* stream) {
+    if (!w_re || !w_im || !wfrag || Cout <= 0 || Cin_used <= 0 || Cin_used > Cin_total || (Cin_used % 8)) return IDV_EINVAL;
+    const int Mtiles = ((2 * Cout + 127) / 128) * 4;
+    const int nchunk = (2 * Cin_used) / 16;
+    long long n = (long long)Mtiles * nchunk * 10 * 2 * 64;
+    long long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_cconv_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w_re, w_im, fold, Cout,
+                       Cin_total, Cin_used, transposed, nchunk, Mtiles, (uint4*)wfrag);
+    return idv_launch_status();
+}
+
+extern "C" int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div,
+                                      const void* wfrag_bf16, const float* bias, const float* prelu_slope, float* out,
+                                      double* stats, int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp,
+                                      int t_valid_out, void* stream) {
+    if (!x0 || !wfrag_bf16 || !bias || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    if (!idv_cconv_bf16_supported(transposed, C0, C1, x1_div < 1 ? 1 : x1_div, Cout)) return IDV_EINVAL;
+    if (C1 > 0 && (!x1 || Jp1 != Jp || (reinterpret_cast<uintptr_t>(x1) & 15))) return IDV_EINVAL;
+    if ((Jp % 4) || (reinterpret_cast<uintptr_t>(x0) & 15) || (tshift != 0 && tshift != -1)) return IDV_EINVAL;
+    CgemmArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1;
+    a.Fin = Fin;
+    a.Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.Jp1 = Jp1; a.x1_div = 1;
+    a.wfrag = (const float*)wfrag_bf16; a.bias = bias; a.slope = prelu_slope; a.out = out;
+    a.M = 2 * Cout; a.Mtiles = (a.M + 31) / 32; a.cplx_rows = 1; a.Cout = Cout;
+    a.tshift = tshift; a.t_valid = t_valid_out; a.stats = stats; a.ldo = 0; a.nB = B;
+    if (Jp < a.J) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = transposed ? Fin : a.Fout;
+    const bool fo5 = waste(rows, 5) <= waste(rows, 3);
+    const bool wide = a.M >= 128;                            // 4 row tiles per workgroup when the layer has them
+#define IDV_BF16_DISPATCH(MODE)                                                                              \
+    if (stats) {                                                                                             \
+        if (wide) return fo5 ? launch_bf16<MODE, 4, 1, 5, 1, true>(a, st) : launch_bf16<MODE, 4, 1, 3, 2, true>(a, st);   \
+        return fo5 ? launch_bf16<MODE, 2, 2, 5, 1, true>(a, st) : launch_bf16<MODE, 2, 2, 3, 1, true>(a, st);             \
+    } else {                                                                                                 \
+        if (wide) return fo5 ? launch_bf16<MODE, 4, 1, 5, 1, false>(a, st) : launch_bf16<MODE, 4, 1, 3, 2, false>(a, st); \
+        return fo5 ? launch_bf16<MODE, 2, 2, 5, 1, false>(a, st) : launch_bf16<MODE, 2, 2, 3, 1, false>(a, st);           \
+    }
+    if (transposed) {
+        IDV_BF16_DISPATCH(IDV_TCONV)
+    } else {
+        IDV_BF16_DISPATCH(IDV_CONV)
+    }
+#undef IDV_BF16_DISPATCH
+}

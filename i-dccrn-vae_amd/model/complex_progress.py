@@ -78,6 +78,7 @@ class _ComplexConvBase(nn.Module):
         self.in_channel, self.out_channel = in_channel, out_channel
         self._cfg = (_pair(kernel_size), _pair(stride), _pair(padding), _pair(dilation), groups, bias, _pair(output_padding))
         self._cache = _PackCache()
+        self._cache_bf16 = _PackCache()
 
     @property
     def _re(self):
@@ -101,6 +102,11 @@ class _ComplexConvBase(nn.Module):
         return self._cache.get(tensors, cin_used, lambda: ops.pack_cconv(
             re.weight.detach(), im.weight.detach(), re.bias.detach(), im.bias.detach(), fold, cin_used, self._transposed))
 
+    def packed_bf16(self, fold: Optional[torch.Tensor], cin_used: Optional[int] = None):
+        re, im = self._re, self._im
+        return self._cache_bf16.get((re.weight, im.weight, fold), cin_used, lambda: ops.pack_cconv_bf16(
+            re.weight.detach(), im.weight.detach(), fold, cin_used, self._transposed))
+
     def forward_planar(self, x: Planar, *, skip: Optional[Planar] = None, skip_div: int = 1, fold=None, slope=None,
                        stats=None, zero_skip: bool = False) -> Planar:
         self._check_supported()
@@ -108,8 +114,12 @@ class _ComplexConvBase(nn.Module):
         if not zero_skip and x.C + (skip.C if skip is not None else 0) != self.in_channel:
             raise RuntimeError(f"expected {self.in_channel} input channels, got {x.C} + {skip.C if skip is not None else 0}")
         wfrag, bias = self.packed(fold, cin_used)
+        wbf = None
+        c1 = skip.C if skip is not None else 0
+        if ops.PRECISION == "bf16x3" and ops.bf16_supported(self._transposed, x.C, c1, skip_div, self.out_channel):
+            wbf = self.packed_bf16(fold, cin_used)
         return ops.cconv2d(x, wfrag, bias, self.out_channel, transposed=self._transposed, causal=self._causal,
-                           slope=slope, skip=skip, skip_div=skip_div, stats=stats)
+                           slope=slope, skip=skip, skip_div=skip_div, stats=stats, wfrag_bf16=wbf)
 
     def forward(self, x):
         return tag5(self.forward_planar(planar_of(x)))

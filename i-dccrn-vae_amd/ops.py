@@ -3,6 +3,7 @@ idv_* operator.  PyTorch is used for device memory and streams only; all arithme
 path happens inside libidccrn_hip.so."""
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -11,6 +12,18 @@ from . import _lib as L
 from ._lib import call, p, i, f, d, ll, stream_ptr
 
 SLACK = 256
+
+# Arithmetic of the complex conv / transposed-conv contraction:
+#   "fp32"   exact fp32 MFMA (v_mfma_f32_32x32x2_f32)                       -- default
+#   "bf16x3" split-precision bf16 MFMA, fp32 accumulate (3 MFMAs per k block) -- ~1e-5 waveform error, ~2x faster
+PRECISION = os.environ.get("IDV_PRECISION", "fp32")
+
+
+def set_precision(mode: str):
+    global PRECISION
+    if mode not in ("fp32", "bf16x3"):
+        raise ValueError("precision must be 'fp32' or 'bf16x3'")
+    PRECISION = mode
 
 
 def bucket(n: int) -> int:
@@ -116,6 +129,25 @@ def pack_cconv(w_re, w_im, b_re, b_im, fold, cin_used: Optional[int] = None, tra
     return wfrag, bias
 
 
+def bf16_supported(transposed: bool, c0: int, c1: int, skip_div: int, cout: int) -> bool:
+    return bool(L.lib().idv_cconv_bf16_supported(i(1 if transposed else 0), i(c0), i(c1), i(skip_div), i(cout)))
+
+
+def pack_cconv_bf16(w_re, w_im, fold, cin_used: Optional[int] = None, transposed=False):
+    """-> split-bf16 weight fragments (uint8 tensor) for idv_cconv2d_bf16x3_fwd."""
+    if transposed:
+        cin_total, cout = w_re.shape[0], w_re.shape[1]
+    else:
+        cout, cin_total = w_re.shape[0], w_re.shape[1]
+    cin_used = cin_total if cin_used is None else cin_used
+    L.lib().idv_cconv_bf16_wfrag_bytes.restype = L._L
+    nbytes = L.lib().idv_cconv_bf16_wfrag_bytes(i(cout), i(cin_used))
+    wfrag = torch.empty(int(nbytes), dtype=torch.uint8, device=w_re.device)
+    call("idv_pack_cconv_bf16", p(w_re.contiguous()), p(w_im.contiguous()), p(fold), i(cout), i(cin_total), i(cin_used),
+         i(1 if transposed else 0), p(wfrag), stream_ptr())
+    return wfrag
+
+
 def pack_pw(w, bias):
     M, K = w.shape
     mt = mtiles_alloc(M)
@@ -134,7 +166,8 @@ LAUNCH_LOG = None
 
 
 def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True, slope=None, skip: Optional[Planar] = None,
-            skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None) -> Planar:
+            skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None,
+            wfrag_bf16: Optional[torch.Tensor] = None) -> Planar:
     """(causal_)ComplexConv2d / (causal_)ComplexConvTranspose2d forward on planar activations."""
     Fout = 2 * x.F - 1 if transposed else (x.F - 1) // 2 + 1
     if causal:
@@ -153,6 +186,15 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
         macs = 4 * (x.C + c1) * cout * 10 * pos
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+    if wfrag_bf16 is not None:
+        cfg = -abs(cfg) if LAUNCH_LOG is not None else 0
+        call("idv_cconv2d_bf16x3_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
+             i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag_bf16), p(bias), p(slope), out.ptr(), p(stats),
+             i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+        if LAUNCH_LOG is not None:
+            ev1.record()
+            LAUNCH_LOG.append((cfg, macs, ev0, ev1))
+        return out
     call("idv_cconv2d_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
          i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag), p(bias), p(slope), out.ptr(), p(stats),
          i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())

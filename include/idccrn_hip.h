@@ -80,6 +80,20 @@ int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, i
                     const float* bias, const float* prelu_slope, float* out, double* stats, int transposed,
                     int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
 
+/* Split-precision variant of idv_cconv2d_fwd (same reference lines): operands split into two bf16 (x = hi + lo),
+ * w*x ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi accumulated in fp32 on the bf16 MFMA (relative error ~2^-16 per
+ * product; waveform parity vs the fp32 path ~1e-5, north_star tolerance 1e-3).  Needs C0 % 8 == 0, C1 % 8 == 0,
+ * x1_div == 1, Cout >= 32, 16-byte aligned rows (idv_cconv_bf16_supported); callers fall back to
+ * idv_cconv2d_fwd otherwise.  wfrag_bf16: idv_pack_cconv_bf16 (idv_cconv_bf16_wfrag_bytes bytes);
+ * bias: the fp32 bias vector produced by idv_pack_cconv. */
+long long idv_cconv_bf16_wfrag_bytes(int Cout, int cin_used);
+int idv_cconv_bf16_supported(int transposed, int C0, int C1, int x1_div, int Cout);
+int idv_pack_cconv_bf16(const float* w_re, const float* w_im, const float* fold, int Cout, int Cin_total, int Cin_used,
+                        int transposed, void* wfrag, void* stream);
+int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const void* wfrag_bf16,
+                           const float* bias, const float* prelu_slope, float* out, double* stats, int transposed,
+                           int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
+
 /* out[m][j] = bias[m] + sum_k w[m][k] x[k][j] over K planes of stride Jp: ComplexDense.forward
  * (complex_progress.py:83-89, one call per real/imag linear), the LSTM input projections, and the
  * DFT / inverse DFT.  swap=1 writes out[((tp-1)*B + b)*ldo + m] instead of planar rows. */

@@ -324,3 +324,92 @@ def test_invalid_arguments_are_reported(amd):
     L = amd._lib
     with pytest.raises(L.IdvError):
         L.call("idv_sisnr", L.p(None), L.i(1), L.i(1), L.p(None), L.i(1), L.i(1), L.i(1), L.p(None), L.p(None), L.stream_ptr())
+
+
+# ----------------------------------------------------------------------------- split-precision (bf16x3) path
+@pytest.mark.parametrize("causal,transposed,cin,cout,F,T,B,skip_c", [
+    (True, False, 32, 64, 65, 70, 2, 0), (True, False, 16, 32, 17, 130, 3, 0), (False, False, 8, 32, 33, 40, 2, 0),
+    (True, True, 16, 64, 9, 70, 2, 16), (True, True, 32, 32, 5, 140, 3, 0), (True, True, 64, 128, 17, 40, 2, 64),
+    (True, False, 128, 128, 33, 70, 1, 0), (True, True, 8, 64, 33, 30, 2, 8),
+])
+def test_cconv_bf16x3(ops, causal, transposed, cin, cout, F, T, B, skip_c):
+    """bf16x3 split-precision contraction vs the oracle: per-operator 2e-4 (product error ~2^-16), guard columns exact."""
+    g = torch.Generator().manual_seed(11)
+    dev = "cuda"
+    cin_tot = cin + skip_c
+    x = torch.randn(B, cin, F, T, 2, generator=g)
+    shape = (cin_tot, cout, 5, 2) if transposed else (cout, cin_tot, 5, 2)
+    wr, wi = torch.randn(shape, generator=g) * 0.1, torch.randn(shape, generator=g) * 0.1
+    br, bi = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    xin, sk = x, None
+    if skip_c:
+        sk = torch.randn(B, skip_c, F, T, 2, generator=g)
+        xin = torch.cat([x, sk], dim=1)
+    if transposed:
+        want = O.complex_conv_transpose2d(xin.double(), wr.double(), br.double(), wi.double(), bi.double(), (2, 1), (2, 0), causal)
+    else:
+        want = O.complex_conv2d(xin.double(), wr.double(), br.double(), wi.double(), bi.double(), (2, 1),
+                                (2, 1) if causal else (2, 0), causal)
+    C = cout
+    mom = torch.stack([torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1, 0.5 + torch.rand(C, generator=g),
+                       0.1 * torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)])
+    gam = [1 + 0.1 * torch.randn(C, generator=g), torch.randn(C, generator=g), 1 + 0.1 * torch.randn(C, generator=g)]
+    bet = [0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)]
+    want = O.prelu(O.cbn_whiten_affine(want.float(), mom[0], mom[1], mom[2], mom[3], mom[4], gam[0], gam[1], gam[2], bet[0], bet[1]),
+                   torch.tensor(0.2))
+    fold = ops.cbn_fold(mom.to(dev), *[t.to(dev) for t in gam], *[t.to(dev) for t in bet])
+    Tp = max(T, want.shape[3]) + 1
+    xp = ops.Planar.from_tensor5(x.to(dev), Tp)
+    skp = ops.Planar.from_tensor5(sk.to(dev), Tp) if sk is not None else None
+    assert ops.bf16_supported(transposed, cin, skip_c, 1, cout)
+    wfrag, bias = ops.pack_cconv(wr.to(dev), wi.to(dev), br.to(dev), bi.to(dev), fold, transposed=transposed)
+    wbf = ops.pack_cconv_bf16(wr.to(dev), wi.to(dev), fold, transposed=transposed)
+    slope = torch.tensor([0.2], device=dev)
+    y = ops.cconv2d(xp, wfrag, bias, cout, transposed=transposed, causal=causal, slope=slope, skip=skp, wfrag_bf16=wbf)
+    y32 = ops.cconv2d(xp, wfrag, bias, cout, transposed=transposed, causal=causal, slope=slope, skip=skp)
+    got = y.tensor5().cpu()
+    assert got.shape == want.shape
+    e16, e32 = relerr(got, want), relerr(y32.tensor5().cpu(), want)
+    assert e32 < TOL and e16 < 2e-4, (e16, e32)
+    assert float(y.planes()[..., 0].abs().max()) == 0.0
+    if y.planes().shape[-1] > y.T + 1:
+        assert float(y.planes()[..., y.T + 1:].abs().max()) == 0.0
+
+
+def test_bf16x3_train_stats_and_model(ops, amd, golden):
+    """bf16x3 end to end: the full-size DCCRN-CL golden waveform within 1e-3 (north_star tolerance) and the
+    train-mode moments of the split-precision conv."""
+    import importlib
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    d = golden("dccrn_full_eval")
+    np_ = O.net_params(True, 32)
+    m = pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, [0, 1, 2, 3, 4, 5], "mask", False, None, None)
+    m.load_state_dict(O.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, int(d["seed"])))
+    m = m.cuda()
+    x = T_(d["x"]).cuda()
+    try:
+        ops.set_precision("bf16x3")
+        clean, _ = m(x, train=False)
+        e = relerr(clean.cpu(), T_(d["clean"]))
+        assert e < 1e-3, e
+        # reduced-width model in train mode (batch statistics from the split-precision epilogue)
+        np4 = O.net_params(True, 8)
+        m2 = pm.DCCRN_(NFFT, HOP, np4, True, "cuda", WIN, [0, 1, 2, 3, 4, 5], "mask", False, None, None)
+        sd = O.synth_state_dict({k: tuple(v.shape) for k, v in m2.state_dict().items()}, 9)
+        m2.load_state_dict(sd)
+        m2 = m2.cuda()
+        g = torch.Generator().manual_seed(4)
+        xs = torch.randn(2, 1600, generator=g) * 0.1
+        c16, _ = m2(xs.cuda(), train=True)
+        ops.set_precision("fp32")
+        m3 = pm.DCCRN_(NFFT, HOP, np4, True, "cuda", WIN, [0, 1, 2, 3, 4, 5], "mask", False, None, None)
+        m3.load_state_dict(sd)
+        m3 = m3.cuda()
+        c32, _ = m3(xs.cuda(), train=True)
+        assert relerr(c16.cpu(), c32.cpu()) < 1e-3
+        for k, v in m3.state_dict().items():
+            if k.endswith("Vrr"):
+                assert relerr(m2.state_dict()[k].cpu(), v.cpu()) < 1e-3, k
+    finally:
+        ops.set_precision("fp32")
+    print("bf16x3 full-size waveform rel err vs reference golden:", e)
