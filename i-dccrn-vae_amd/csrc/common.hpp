@@ -35,4 +35,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// gate non-linearities on the hardware exp2 / rcp (about 1 ulp each): absolute error ~1e-7, which is what the
+// LSTM cell needs; tanh(x) = 2 sigmoid(2x) - 1.  They sit on the per-step critical path of the recurrence.
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.0f;
+}

@@ -104,10 +104,10 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(const RecArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float ig = sigmoidf_(acc[u][0][r]), fg = sigmoidf_(acc[u][1][r]);
-                    const float gv = tanhf(acc[u][2][r]), og = sigmoidf_(acc[u][3][r]);
+                    const float gv = tanhf_(acc[u][2][r]), og = sigmoidf_(acc[u][3][r]);
                     const float cn = fg * creg[u][r] + ig * gv;
                     creg[u][r] = cn;
-                    hv[r] = og * tanhf(cn);
+                    hv[r] = og * tanhf_(cn);
                     const int row = rq * 4 + r;
                     if (b0 + row < a.B) hout[(rowbase + row) * H + unit] = hv[r];
                 }
@@ -141,10 +141,10 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(const RecArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
-                    const float gv = tanhf(acc[2][r]), og = sigmoidf_(acc[3][r]);
+                    const float gv = tanhf_(acc[2][r]), og = sigmoidf_(acc[3][r]);
                     const float cn = fg * cv[r] + ig * gv;
                     cv[r] = cn;
-                    hv[r] = og * tanhf(cn);
+                    hv[r] = og * tanhf_(cn);
                     const int row = rq * 4 + r;
                     if (b0 + row < a.B) hout[(rowbase + row) * H + unit] = hv[r];
                 }
@@ -152,6 +152,117 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(const RecArgs a) {
                 *(f32x4*)&hn[unit * 16 + rq * 4] = hv;
             }
         }
+        __syncthreads();
+    }
+}
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// Split-precision recurrence for H = 128: h and W_hh as (hi, lo) bf16 pairs, gates = h*W on
+// v_mfma_f32_16x16x32_bf16 with the three cross terms (fp32 accumulate) - 96 MFMAs of 16 cycles per step instead
+// of 256 of 32.  W_hh (hi+lo: the same 256 VGPRs as the fp32 slice) stays in registers for all T steps; h lives
+// in LDS as [seq][k] bf16 images with the 16-byte chunk index XOR-ed with the row (conflict-free b128 reads).
+__global__ __launch_bounds__(256, 1) void lstm_rec_bf16_kernel(const RecArgs a) {
+    constexpr int H = 128;
+    __shared__ __attribute__((aligned(16))) unsigned short hs[2][2][16 * H];     // [buffer][hi|lo][seq][k]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int run = blockIdx.y, z = run >> 1, s = run & 1;
+    const int b0 = blockIdx.x * 16;
+    const int col = lane & 15, rq = lane >> 4;
+    const float* g = a.g + z * a.g_run_z + s * a.g_run_s;
+    // bf16 fragments follow the fp32 ones in the packed blob: [set][tile][kb][split][lane] x 16 B
+    const uint4* wb = (const uint4*)(a.whh + (size_t)2 * 4 * H * H) + (size_t)s * 32 * 4 * 2 * 64 + lane;
+    float* hout = a.hout + (size_t)run * a.T * a.B * H;
+
+    for (int e = tid; e < 2 * 2 * 16 * H / 2; e += 256) ((unsigned*)hs)[e] = 0u;
+
+    uint4 breg[2][4][4][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+                    breg[u][gg][kb][sp] = wb[((size_t)(((wave + 4 * u) * 4 + gg) * 4 + kb) * 2 + sp) * 64];
+    float creg[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) creg[u][r] = 0.f;
+
+    f32x4 gcur[2][4], gnxt[2][4];
+    auto load_g = [&](int t, f32x4 (&dst)[2][4]) {
+        const size_t rb = (size_t)t * a.B + b0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (b0 + rq * 4 + r < a.B) ? rq * 4 + r : 0;
+                    dst[u][gg][r] = g[(rb + row) * a.ldg + ((wave + 4 * u) * 4 + gg) * 16 + col];
+                }
+    };
+    load_g(0, gcur);
+    __syncthreads();
+
+    for (int t = 0; t < a.T; ++t) {
+        const unsigned short* hc_hi = hs[t & 1][0];
+        const unsigned short* hc_lo = hs[t & 1][1];
+        unsigned short* hn_hi = hs[(t + 1) & 1][0];
+        unsigned short* hn_lo = hs[(t + 1) & 1][1];
+        const size_t rowbase = (size_t)t * a.B + b0;
+        if (t + 1 < a.T) load_g(t + 1, gnxt);
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) acc[u][gg] = gcur[u][gg];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            // A fragment: seq = lane&15, 8 consecutive k = chunk 4*kb + (lane>>4), swizzled with the row
+            const int off = col * H + (((4 * kb + rq) ^ col) & 15) * 8;
+            const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *(const uint4*)(hc_hi + off));
+            const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *(const uint4*)(hc_lo + off));
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, breg[u][gg][kb][0]);
+                    const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, breg[u][gg][kb][1]);
+                    f32x4 c = acc[u][gg];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+                    acc[u][gg] = c;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int unit = (wave + 4 * u) * 16 + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = sigmoidf_(acc[u][0][r]), fg = sigmoidf_(acc[u][1][r]);
+                const float gv = tanhf_(acc[u][2][r]), og = sigmoidf_(acc[u][3][r]);
+                const float cn = fg * creg[u][r] + ig * gv;
+                creg[u][r] = cn;
+                const float hv = og * tanhf_(cn);
+                const int row = rq * 4 + r;
+                if (b0 + row < a.B) hout[(rowbase + row) * H + unit] = hv;
+                const __bf16 hh = (__bf16)hv;
+                const __bf16 hl = (__bf16)(hv - (float)hh);
+                const int o = row * H + ((((unit >> 3) ^ row) & 15) << 3) + (unit & 7);
+                hn_hi[o] = __builtin_bit_cast(unsigned short, hh);
+                hn_lo[o] = __builtin_bit_cast(unsigned short, hl);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) gcur[u][gg] = gnxt[u][gg];
         __syncthreads();
     }
 }
@@ -251,11 +362,11 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs sa) {
             const int row = rq * 4 + r;
             if (b0 + row >= a.B) continue;
             const float ig = sigmoidf_(gate[0][r] + gpre[0][r]), fg = sigmoidf_(gate[1][r] + gpre[1][r]);
-            const float gv = tanhf(gate[2][r] + gpre[2][r]), og = sigmoidf_(gate[3][r] + gpre[3][r]);
+            const float gv = tanhf_(gate[2][r] + gpre[2][r]), og = sigmoidf_(gate[3][r] + gpre[3][r]);
             const size_t ci = (size_t)(b0 + row) * H + unit;
             const float cn = fg * cpre[r] + ig * gv;
             cst[ci] = cn;
-            hout[(rowbase + row) * H + unit] = og * tanhf(cn);
+            hout[(rowbase + row) * H + unit] = og * tanhf_(cn);
         }
     }
 }
@@ -422,9 +533,11 @@ __global__ void zero_tail_kernel(float* __restrict__ act, int planes, int B, int
     }
 }
 
-int launch_rec(const RecArgs& ra, float* cstate, hipStream_t st) {
+int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
     dim3 grid((ra.B + 15) / 16, 4);
-    if (ra.H == 128) {
+    if (ra.H == 128 && (flags & 1)) {
+        hipLaunchKernelGGL(lstm_rec_bf16_kernel, grid, dim3(256), 0, st, ra);
+    } else if (ra.H == 128) {
         const size_t smem = (size_t)2 * 128 * 16 * sizeof(float);
         hipLaunchKernelGGL(lstm_rec_kernel<true>, grid, dim3(256), smem, st, ra);
     } else if (ra.H % 32 == 0 && cstate) {
@@ -455,7 +568,7 @@ extern "C" long long idv_clstm_work_floats(int H, int B, int T, int Jp) {
 
 extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
                              const float* wih1, const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp,
-                             float* work, float* out, void* stream) {
+                             float* work, float* out, int flags, void* stream) {
     if (!x || !wih0 || !bih0 || !whh0 || !wih1 || !bih1 || !whh1 || !work || !out) return IDV_EINVAL;
     if (H <= 0 || (H % 16) || K <= 0 || (K & 1) || B <= 0 || T <= 0 || Tp < T + 1 || Jp < B * Tp) return IDV_EINVAL;
     if ((size_t)3 * H * 16 * sizeof(float) > 160 * 1024) return IDV_EINVAL;
@@ -473,7 +586,7 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
         if (rc) return rc;
     }
     RecArgs r0{G, TB * 8 * H, 4LL * H, 8 * H, whh0, h0, H, B, T};
-    if ((rc = launch_rec(r0, cstate, st))) return rc;
+    if ((rc = launch_rec(r0, cstate, flags, st))) return rc;
     // layer 1 input projection from h0 (row-major), per run
     const int KS = ((H + 7) / 8) * 4;
     dim3 ggrid((unsigned)((TB + 31) / 32), 4);
@@ -500,7 +613,7 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     if ((rc = idv_launch_status())) return rc;
     // G1 is [run][TB][4H] with run = 2z + s
     RecArgs r1{G, 2 * TB * 4 * H, TB * 4 * H, 4 * H, whh1, h1, H, B, T};
-    if ((rc = launch_rec(r1, cstate, st))) return rc;
+    if ((rc = launch_rec(r1, cstate, flags, st))) return rc;
     hipLaunchKernelGGL(lstm_combine_kernel, dim3((T + 31) / 32, (H + 31) / 32, B), dim3(256), 0, st, h1, H, B, T, Tp, Jp, out);
     const long long ntail = 2LL * H * B * (Tp - 1 - T);
     if (ntail > 0)

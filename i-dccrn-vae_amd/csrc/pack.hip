@@ -123,6 +123,39 @@ __global__ void pack_lstm_hh_kernel(const float* __restrict__ w_re, const float*
     }
 }
 
+// split-bf16 recurrent weights appended to the fp32 fragments: [set][tile][kb][hi|lo][lane] x 16 B, lane l holds
+// B[k = 32*kb + 8*(l>>4) + j][n = l&15] = W_hh[row(colp = tile*16 + n)][k], j = 0..7
+__global__ void pack_lstm_hh_bf16_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im, int H,
+                                         uint4* __restrict__ out) {
+    const int NTl = H / 4, KB = H / 32;
+    const long long n = 2LL * NTl * KB * 2 * 64;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        long long t = idx >> 6;
+        const int sp = (int)(t & 1); t >>= 1;
+        const int kb = (int)(t % KB); t /= KB;
+        const int tile = (int)(t % NTl);
+        const int set = (int)(t / NTl);
+        const float* w = set ? w_im : w_re;
+        const int row = lstm_src_row(tile * 16 + (lane & 15), H);
+        unsigned o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float x = w[(size_t)row * H + 32 * kb + 8 * (lane >> 4) + 2 * q + e];
+                const float hi = (float)(__bf16)x;
+                v[e] = sp == 0 ? x : x - hi;
+            }
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            bf2 pk = {(__bf16)v[0], (__bf16)v[1]};
+            o[q] = __builtin_bit_cast(unsigned, pk);
+        }
+        out[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 __global__ void cbn_fold_kernel(const float* __restrict__ mom, const float* __restrict__ g_rr, const float* __restrict__ g_ri,
                                 const float* __restrict__ g_ii, const float* __restrict__ b_r, const float* __restrict__ b_i,
                                 int C, float* __restrict__ fold) {
@@ -237,6 +270,9 @@ extern "C" int idv_pack_lstm_hh(const float* w_hh_re, const float* w_hh_im, int 
     if (!w_hh_re || !w_hh_im || !whh_frag || H <= 0 || (H % 16)) return IDV_EINVAL;
     hipLaunchKernelGGL(pack_lstm_hh_kernel, dim3(grid_for(2LL * 4 * H * H)), dim3(256), 0, (hipStream_t)stream, w_hh_re,
                        w_hh_im, H, whh_frag);
+    if (H % 32 == 0)
+        hipLaunchKernelGGL(pack_lstm_hh_bf16_kernel, dim3(grid_for(2LL * H * H / 4)), dim3(256), 0, (hipStream_t)stream, w_hh_re,
+                           w_hh_im, H, (uint4*)(whh_frag + (size_t)2 * 4 * H * H));
     return idv_launch_status();
 }
 

@@ -222,7 +222,7 @@ def pack_lstm(sd_get, H: int, K: int, layer: int, device):
     call("idv_pack_lstm_ih", p(g(f"lstm_re.weight_ih_l{l}")), p(g(f"lstm_re.bias_ih_l{l}")), p(g(f"lstm_re.bias_hh_l{l}")),
          p(g(f"lstm_im.weight_ih_l{l}")), p(g(f"lstm_im.bias_ih_l{l}")), p(g(f"lstm_im.bias_hh_l{l}")), i(H), i(K),
          p(wih), p(bih), stream_ptr())
-    whh = torch.empty(2 * 4 * H * H, dtype=torch.float32, device=device)
+    whh = torch.empty(4 * 4 * H * H, dtype=torch.float32, device=device)
     call("idv_pack_lstm_hh", p(g(f"lstm_re.weight_hh_l{l}")), p(g(f"lstm_im.weight_hh_l{l}")), i(H), p(whh), stream_ptr())
     return wih, bih, whh
 
@@ -234,7 +234,8 @@ def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
     nwork = L.lib().idv_clstm_work_floats(i(H), i(x.B), i(x.T), i(x.Jp))
     work = torch.empty(bucket(int(nwork)), dtype=torch.float32, device=x.buf.device)
     call("idv_clstm_fwd", x.ptr(), i(K), p(packed0[0]), p(packed0[1]), p(packed0[2]), p(packed1[0]), p(packed1[1]),
-         p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), stream_ptr())
+         p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), i(1 if PRECISION == "bf16x3" else 0),
+         stream_ptr())
     return out
 
 

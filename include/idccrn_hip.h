@@ -57,7 +57,8 @@ int idv_pack_pw(const float* w, const float* bias, int M, int K, float* wfrag, f
 int idv_pack_lstm_ih(const float* w_ih_re, const float* b_ih_re, const float* b_hh_re, const float* w_ih_im,
                      const float* b_ih_im, const float* b_hh_im, int H, int K, float* wfrag, float* bias_out,
                      void* stream);
-/* Recurrent weights w_hh_*: [4H][H] -> fragment order of the recurrent kernel, 2*4H*H floats. */
+/* Recurrent weights w_hh_*: [4H][H] -> fragment order of the recurrent kernels: 2*4H*H floats of fp32 fragments
+ * followed by the same number of bytes of split-bf16 (hi, lo) fragments; whh_frag holds 4*4H*H floats. */
 int idv_pack_lstm_hh(const float* w_hh_re, const float* w_hh_im, int H, float* whh_frag, void* stream);
 
 /* Windowed DFT / inverse-DFT matrices of torch.stft / torch.istft as used by STFT.forward /
@@ -132,12 +133,12 @@ int idv_mask_apply(const float* mask, const float* X, int x_div, int JpX, float*
 int idv_planar_to_complex(const float* act, float* out_c, int F, int B, int T, int Tp, int Jp, void* stream);
 
 /* ComplexLSTM.forward (complex_progress.py:50-74): four 2-layer LSTM passes, real = rr - ii,
- * imag = ir + ri.  x: planar [2][K][Jp]; out: planar [2][H][Jp].  wihN / bihN: idv_pack_lstm_ih of layer
+ * imag = ir + ri.  x: planar [2][K][Jp]; out: planar [2][H][Jp].  flags bit 0: split-bf16 recurrence (H = 128).  wihN / bihN: idv_pack_lstm_ih of layer
  * N, whhN: idv_pack_lstm_hh of layer N.  work: idv_clstm_work_floats(H, B, T, Jp) floats. */
 long long idv_clstm_work_floats(int H, int B, int T, int Jp);   /* 24*T*B*H + 4*B*H + 4*H*Jp */
 int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0, const float* wih1,
                   const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp, float* work, float* out,
-                  void* stream);
+                  int flags, void* stream);
 
 /* reparameterization (pvae_module.py:1832-1886) with the two randn draws supplied by the caller.
  * lat: planar LSTM output [2][Hl][Jp]; miu/log_sigma/delta are channel offsets off_miu/off_ls/off_dl

@@ -413,3 +413,29 @@ def test_bf16x3_train_stats_and_model(ops, amd, golden):
     finally:
         ops.set_precision("fp32")
     print("bf16x3 full-size waveform rel err vs reference golden:", e)
+
+
+@pytest.mark.parametrize("T,B,I", [(40, 5, 64), (641, 3, 160)])
+def test_clstm_bf16x3(ops, T, B, I):
+    """Split-bf16 recurrence (H = 128) against the fp64 oracle: 641 recurrent steps must not accumulate error."""
+    H = 128
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(T, B, I, 2, generator=g)
+    names = [f"lstm_{s}.{w}_l{l}" for s in ("re", "im") for l in (0, 1) for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    sd = {}
+    for n in names:
+        l = int(n[-1])
+        shape = (4 * H, I if l == 0 else H) if "weight_ih" in n else ((4 * H, H) if "weight_hh" in n else (4 * H,))
+        sd[n] = O.synth_tensor(n, shape, 5) * (3.0 if "weight" in n else 1.0)
+    want = O.complex_lstm(x.double(), {k: v.double() for k, v in sd.items()}, "", 2).float()
+    xp = ops.Planar.from_tensor5(x.permute(1, 2, 0, 3).unsqueeze(2).cuda())
+    get = lambda n: sd[n].cuda()
+    p0, p1 = ops.pack_lstm(get, H, I, 0, "cuda"), ops.pack_lstm(get, H, H, 1, "cuda")
+    try:
+        ops.set_precision("bf16x3")
+        got16 = ops.clstm(xp, p0, p1, H).channel_slice(0, H).cpu().permute(1, 0, 2, 3)
+    finally:
+        ops.set_precision("fp32")
+    got32 = ops.clstm(xp, p0, p1, H).channel_slice(0, H).cpu().permute(1, 0, 2, 3)
+    e16, e32 = relerr(got16, want), relerr(got32, want)
+    assert e32 < TOL and e16 < 1e-4, (e16, e32)
