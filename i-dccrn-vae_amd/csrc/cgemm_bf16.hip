@@ -35,7 +35,6 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_bf16_kernel(const CgemmA
     constexpr int BUF = 2 * IMG;                     // hi + lo
     constexpr int NTASK = FR * PS4 * 2;              // (row, 4-column group, channel octet)
     constexpr int NLD = (NTASK + NT - 1) / NT;
-    constexpr int RING = 5;
 
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
 
@@ -128,8 +127,10 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_bf16_kernel(const CgemmA
                     hi.z = pack_bf16(v[4], v[5]); hi.w = pack_bf16(v[6], v[7]);
                     lo.x = pack_bf16(r[0], r[1]); lo.y = pack_bf16(r[2], r[3]);
                     lo.z = pack_bf16(r[4], r[5]); lo.w = pack_bf16(r[6], r[7]);
-                    // (row, column) index = rest*4 + q because rest = fr*PS4 + c4 and PS = 4*PS4
-                    unsigned short* d = dst + ((size_t)(rest * 4 + q) * 16 + 8 * oct);
+                    // image[fr][octet][column][8 channels]: lanes of one MFMA operand half read consecutive 16-byte
+                    // slots (bank-conflict free); rest = fr*PS4 + c4
+                    const int frw = rest / PS4, c4w = rest - frw * PS4;
+                    unsigned short* d = dst + ((size_t)((frw * 2 + oct) * PS + 4 * c4w + q) * 8);
                     *(uint4*)d = hi;
                     *(uint4*)(d + IMG) = lo;
                 }
@@ -137,17 +138,21 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_bf16_kernel(const CgemmA
         }
     };
 
-    // ---- weight ring ---------------------------------------------------------------------------------
-    const int NTAP = nchunk * 10;
-    const uint4* wstream = (const uint4*)a.wfrag + (size_t)mt0 * NTAP * 128 + lane;
-    uint4 a_hi[RING], a_lo[RING];
-    auto load_a = [&](int g, int slot) {
-        const int gg = g < NTAP ? g : NTAP - 1;            // past the end: harmless re-read
-        a_hi[slot] = wstream[(size_t)gg * 128];
-        a_lo[slot] = wstream[(size_t)gg * 128 + 64];
+    // ---- weight fragments: taps are stored time-tap-major (g = chunk*10 + kt*5 + kf); one "phase" = the five
+    // frequency taps of one time tap.  The phase after the current one is prefetched into the other half.
+    const int NPH = nchunk * 2;
+    const uint4* wstream = (const uint4*)a.wfrag + (size_t)mt0 * NPH * 5 * 128 + lane;
+    uint4 a_hi[2][5], a_lo[2][5];
+    auto load_a = [&](int ph, uint4 (&dh)[5], uint4 (&dl)[5]) {
+        const int pp = ph < NPH ? ph : NPH - 1;            // past the end: harmless re-read
+#pragma unroll
+        for (int kf = 0; kf < 5; ++kf) {
+            dh[kf] = wstream[(size_t)(pp * 5 + kf) * 128];
+            dl[kf] = wstream[(size_t)(pp * 5 + kf) * 128 + 64];
+        }
     };
 
-    // ---- activation fragments ------------------------------------------------------------------------
+    // ---- activation fragments: one LDS row (fr) serves every (output row, freq tap) pair that reads it ----
     const int half = lane >> 5, l31 = lane & 31;
     int cbase[2];                                           // column of this lane for time tap kt
 #pragma unroll
@@ -155,43 +160,70 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_bf16_kernel(const CgemmA
         const int toff = (MODE == IDV_CONV) ? kt + a.tshift : -kt;
         cbase[kt] = wn * (JC_W * 32) + l31 + 4 + toff;
     }
+    auto load_b = [&](const unsigned short* P, int fr, int kt, uint4 (&bh)[JC_W], uint4 (&bl)[JC_W]) {
+#pragma unroll
+        for (int jc = 0; jc < JC_W; ++jc) {
+            const unsigned short* src = P + ((size_t)((fr * 2 + half) * PS + cbase[kt] + jc * 32) * 8);
+            bh[jc] = *(const uint4*)src;
+            bl[jc] = *(const uint4*)(src + IMG);
+        }
+    };
 
     stage_load(0);
-#pragma unroll
-    for (int s = 0; s < RING - 1; ++s) load_a(s, s);
+    load_a(0, a_hi[0], a_lo[0]);
     stage_store(smem16);
+#pragma unroll
+    for (int kf = 0; kf < 5; ++kf) {
+        asm volatile("" : "+v"(a_hi[0][kf].x), "+v"(a_hi[0][kf].y), "+v"(a_hi[0][kf].z), "+v"(a_hi[0][kf].w));
+        asm volatile("" : "+v"(a_lo[0][kf].x), "+v"(a_lo[0][kf].y), "+v"(a_lo[0][kf].z), "+v"(a_lo[0][kf].w));
+    }
     __syncthreads();
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const unsigned short* P = smem16 + (chunk & 1) * BUF;
         const int nxt = (chunk + 1 < nchunk) ? chunk + 1 : chunk;
 #pragma unroll
-        for (int tap = 0; tap < 10; ++tap) {
-            const int kf = tap >> 1, kt = tap & 1;
-            load_a(chunk * 10 + tap + RING - 1, (tap + RING - 1) % RING);
-            if (tap == 0) stage_load(nxt);
-            if (tap == 8) stage_store(smem16 + ((chunk + 1) & 1) * BUF);
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi[tap % RING]);
-            const bf16x8 al = __builtin_bit_cast(bf16x8, a_lo[tap % RING]);
+        for (int kt = 0; kt < 2; ++kt) {
+            uint4 b_h[JC_W], b_l[JC_W], n_h[JC_W], n_l[JC_W];
+            load_b(P, 0, kt, b_h, b_l);
 #pragma unroll
-            for (int rt = 0; rt < ROWS; ++rt) {
-                int fr;
-                if (MODE == IDV_CONV) {
-                    fr = 2 * rt + kf;
-                } else {
-                    if ((rt & 1) != (kf & 1)) continue;
-                    fr = (rt >> 1) + 2 - (kf >> 1);
+            for (int fr = 0; fr < FR; ++fr) {
+                if (fr + 1 < FR) load_b(P, fr + 1, kt, n_h, n_l);
+                __builtin_amdgcn_sched_barrier(0);
+                if (fr == 0) {
+                    load_a(chunk * 2 + kt + 1, a_hi[kt ^ 1], a_lo[kt ^ 1]);
+                    if (kt == 0) stage_load(nxt);
                 }
+                if (kt == 1 && fr == FR / 2) stage_store(smem16 + ((chunk + 1) & 1) * BUF);
 #pragma unroll
-                for (int jc = 0; jc < JC_W; ++jc) {
-                    const unsigned short* src = P + ((size_t)(fr * PS + cbase[kt] + jc * 32) * 16 + 8 * half);
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4*)src);
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(src + IMG));
-                    f32x16 c = acc[rt * JC_W + jc];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-                    acc[rt * JC_W + jc] = c;
+                for (int rt = 0; rt < ROWS; ++rt) {
+#pragma unroll
+                    for (int kf = 0; kf < KF; ++kf) {
+                        int frr;
+                        if (MODE == IDV_CONV) {
+                            frr = 2 * rt + kf;
+                        } else {
+                            if ((rt & 1) != (kf & 1)) continue;
+                            frr = (rt >> 1) + 2 - (kf >> 1);
+                        }
+                        if (frr != fr) continue;
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi[kt][kf]);
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, a_lo[kt][kf]);
+#pragma unroll
+                        for (int jc = 0; jc < JC_W; ++jc) {
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, b_h[jc]);
+                            const bf16x8 bl = __builtin_bit_cast(bf16x8, b_l[jc]);
+                            f32x16 c = acc[rt * JC_W + jc];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                            acc[rt * JC_W + jc] = c;
+                        }
+                    }
+                }
+                if (fr + 1 < FR) {
+#pragma unroll
+                    for (int jc = 0; jc < JC_W; ++jc) { b_h[jc] = n_h[jc]; b_l[jc] = n_l[jc]; }
                 }
             }
         }
@@ -304,7 +336,7 @@ __device__ float wprime(const float* w_re, const float* w_im, const float* fold,
 }
 
 // out[mt][g = chunk*10 + tap][split][lane] (uint4 = 8 bf16): lane l holds row mt*32 + (l&31), channels
-// 16*chunk + 8*(l>>5) + 0..7 of tap (kf = tap>>1, kt = tap&1)
+// 16*chunk + 8*(l>>5) + 0..7 of tap (kt = tap/5, kf = tap%5: time-tap-major)
 __global__ void pack_cconv_bf16_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im,
                                        const float* __restrict__ fold, int Cout, int Cin_total, int Cin_used,
                                        int transposed, int nchunk, int Mtiles, uint4* __restrict__ out) {
@@ -321,7 +353,7 @@ __global__ void pack_cconv_bf16_kernel(const float* __restrict__ w_re, const flo
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float w = wprime(w_re, w_im, fold, Cout, Cin_total, Cin_used, transposed, m,
-                                   16 * chunk + 8 * (lane >> 5) + j, tap >> 1, tap & 1);
+                                   16 * chunk + 8 * (lane >> 5) + j, tap % 5, tap / 5);
             v[j] = split == 0 ? w : w - bf16_round(w);
         }
         uint4 o;
