@@ -114,25 +114,33 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_bf16_kernel(const CgemmA
             const int oct = e & 1, rest = e >> 1;
             const unsigned bits = (okbits >> (4 * i)) & 15u;
             if (e < NTASK) {
+                // edge tasks (freq padding, batch head / tail) zero their invalid columns; interior tasks skip it
+                if (bits != 15u) {
+#pragma unroll
+                    for (int p = 0; p < 8; ++p)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) stg[i][p][q] = ((bits >> q) & 1u) ? stg[i][p][q] : 0.f;
+                }
+                const int frw = rest / PS4, c4w = rest - frw * PS4;
+                // image[fr][octet][column][8 channels]: lanes of one MFMA operand half read consecutive 16-byte slots
+                unsigned short* d0 = dst + ((size_t)((frw * 2 + oct) * PS + 4 * c4w) * 8);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float v[8];
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) v[p] = ((bits >> q) & 1u) ? stg[i][p][q] : 0.f;
                     uint4 hi, lo;
-                    float r[8];
+                    unsigned hw[4], lw[4];
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) r[p] = v[p] - bf16_round(v[p]);
-                    hi.x = pack_bf16(v[0], v[1]); hi.y = pack_bf16(v[2], v[3]);
-                    hi.z = pack_bf16(v[4], v[5]); hi.w = pack_bf16(v[6], v[7]);
-                    lo.x = pack_bf16(r[0], r[1]); lo.y = pack_bf16(r[2], r[3]);
-                    lo.z = pack_bf16(r[4], r[5]); lo.w = pack_bf16(r[6], r[7]);
-                    // image[fr][octet][column][8 channels]: lanes of one MFMA operand half read consecutive 16-byte
-                    // slots (bank-conflict free); rest = fr*PS4 + c4
-                    const int frw = rest / PS4, c4w = rest - frw * PS4;
-                    unsigned short* d = dst + ((size_t)((frw * 2 + oct) * PS + 4 * c4w + q) * 8);
-                    *(uint4*)d = hi;
-                    *(uint4*)(d + IMG) = lo;
+                    for (int w = 0; w < 4; ++w) {
+                        const float x0 = stg[i][2 * w][q], x1 = stg[i][2 * w + 1][q];
+                        // hi = truncation to bf16 (one AND), lo = round-to-nearest of the exact remainder
+                        const unsigned u0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u;
+                        const unsigned u1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
+                        hw[w] = (u0 >> 16) | u1;
+                        lw[w] = pack_bf16(x0 - __builtin_bit_cast(float, u0), x1 - __builtin_bit_cast(float, u1));
+                    }
+                    hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                    lo = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                    *(uint4*)(d0 + q * 8) = hi;
+                    *(uint4*)(d0 + q * 8 + IMG) = lo;
                 }
             }
         }
