@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 NFFT, HOP, WIN, LEN = 512, 100, 400, 64000
 SKIP = [0, 1, 2, 3, 4, 5]
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak (2:1-sparsity figures never used)
 METRIC = "4s@16kHz utterances/sec fwd+SI-SNR, DCCRN-CL, 1/2/4/8 MI355X vs host CPU"
 
 
@@ -161,7 +162,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--workload", default="dccrn_cl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("IDV_PRECISION", "fp32"), choices=["fp32", "bf16x3"],
+    ap.add_argument("--precision", default=os.environ.get("IDV_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
                     help="conv contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
 
@@ -213,7 +214,15 @@ def main():
     dt = importlib.import_module("i-dccrn-vae_amd.utils.dist_timing")
     value, elapsed = dt.job_throughput(elapsed, float(utt_per_step * args.steps), device)
 
-    # dominant kernel: group conv launches by cgemm instantiation, HIP-event durations on the launch stream
+    # dominant kernel: group conv launches by kernel instantiation, HIP-event durations on the launch stream
+    def kernel_name(cfg_id):
+        if cfg_id > 0:
+            d = str(cfg_id)
+            mode, t = (1 if len(d) == 7 else 0), d[-6:]
+            return f"void cgemm_kernel<{mode}, {t[0]}, {t[1]}, {t[2]}, {t[3]}, {t[4]}, {t[5]}, false, false, true>(CgemmArgs)"
+        d = str(-cfg_id - 100000).rjust(5, "0")
+        return f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false>(CgemmArgs)"
+
     groups = {}
     for cfg_id, macs, e0, e1 in launches:
         g = groups.setdefault(cfg_id, [0, 0.0, 0])
@@ -226,23 +235,34 @@ def main():
         macs, secs, n = groups[dom]
         tot_macs = sum(g[0] for g in groups.values())
         tot_secs = sum(g[1] for g in groups.values())
-        d = str(abs(dom))
-        mode = "TCONV" if len(d) == 7 else "CONV"
-        t = d[-6:]
-        kname = (f"cgemm_kernel<{mode}, WM={t[0]}, WN={t[1]}, MT_W={t[2]}, FO_T={t[3]}, JC_W={t[4]}, CCK={t[5]}>" if dom > 0
-                 else f"cgemm_bf16_kernel<{mode}> (split-bf16 variant of layer class {d})")
+        split = dom < 0
+        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        ach = 2 * macs / secs / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and args.batch == 64 and args.workload == "dccrn_cl":
+            tk = json.load(open(tpath))["kernels"].get(kernel_name(dom))
+            if tk:
+                traffic = tk["hbm_bytes_per_launch"]
         roofline = {
-            "bound": "mfma", "achieved": round(2 * macs / secs / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(2 * macs / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": kname,
-            "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
+            "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": traffic,
+            "traffic_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from the committed rocprofv3 --pmc passes "
+                            "(profiles/r01_traffic.json, same command, B=64); null when the run differs from that command",
+            "peak_note": ("dense bf16 MFMA peak; achieved counts ALGORITHMIC fp32 flops (4 real convs), the kernel executes 3 bf16 "
+                          "MFMA products per algorithmic product" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+            "kernel": kernel_name(dom), "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
             "algorithmic_gflop_per_launch": round(2 * macs / n / 1e9, 3),
             "all_conv_launches": {"achieved": round(2 * tot_macs / tot_secs / 1e12, 3),
-                                  "frac": round(2 * tot_macs / tot_secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "frac": round(2 * tot_macs / tot_secs / 1e12 / peak, 4),
                                   "share_of_step_time": round(tot_secs / elapsed, 4)},
-            "per_kernel": {str(k): {"tflops": round(2 * v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / args.steps * 1e3, 3)}
+            "per_kernel": {kernel_name(k): {"tflops": round(2 * v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / args.steps * 1e3, 3)}
                            for k, v in sorted(groups.items())},
         }
+        if split:
+            roofline["executed_bf16_tflops"] = round(3 * ach, 1)
+            roofline["frac_executed"] = round(3 * ach / peak, 4)
+            roofline["vs_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 3)
 
     if rank == 0:
         out = {

@@ -385,6 +385,16 @@ extern "C" int idv_cconv_bf16_supported(int transposed, int C0, int C1, int x1_d
     return 1;
 }
 
+// template arguments <MODE, WM, WN, FO_T, JC_W> of the cgemm_bf16_kernel instantiation a layer shape uses, as digits
+extern "C" int idv_cconv_bf16_config(int transposed, int Cout, int Fin) {
+    const int rows = transposed ? Fin : (Fin - 1) / 2 + 1;
+    const bool fo5 = waste(rows, 5) <= waste(rows, 3);
+    const bool wide = 2 * Cout >= 128;
+    const int mode = transposed ? 1 : 0;
+    if (wide) return mode * 10000 + (fo5 ? 4151 : 4132);
+    return mode * 10000 + (fo5 ? 2251 : 2231);
+}
+
 extern "C" int idv_pack_cconv_bf16(const float* w_re, const float* w_im, const float* fold, int Cout, int Cin_total,
                                    int Cin_used, int transposed, void* wfrag, void* stream) {
     if (!w_re || !w_im || !wfrag || Cout <= 0 || Cin_used <= 0 || Cin_used > Cin_total || (Cin_used % 8)) return IDV_EINVAL;
