@@ -8,19 +8,10 @@
 // 8 channel planes x 4 columns (8 aligned float4), converts, and writes 4 + 4 ds_write_b128.
 // Weights: pre-split bf16 fragments [row tile][chunk][tap][hi|lo][lane] x 16 B, streamed from L2 through a
 // 5-tap register ring (4 taps of prefetch distance).
-#include "cgemm.hpp"
+#include "bf16_common.hpp"
 #include "../../include/idccrn_hip.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
 namespace {
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    bf16x2 v = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, v);
-}
-__device__ __forceinline__ float bf16_round(float a) { return (float)(__bf16)a; }
 
 template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS>
 __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_bf16_kernel(const CgemmArgs a) {
@@ -326,22 +317,6 @@ int launch_bf16(const CgemmArgs& a, hipStream_t st) {
 }
 
 inline int waste(int n, int t) { return ((n + t - 1) / t) * t - n; }
-
-// W'(m, cc, kf, kt) of the block matrix [[Wr,-Wi],[Wi,Wr]] with the optional BN fold (same as pack.hip)
-__device__ float wprime(const float* w_re, const float* w_im, const float* fold, int Cout, int Cin_total, int Cin_used,
-                        int transposed, int m, int cc, int kf, int kt) {
-    const int co = m >> 1, ro = m & 1, ci = cc >> 1, ri = cc & 1;
-    if (co >= Cout || ci >= Cin_used) return 0.f;
-    const size_t off = transposed ? (((size_t)ci * Cout + co) * 5 + kf) * 2 + kt
-                                  : (((size_t)co * Cin_total + ci) * 5 + kf) * 2 + kt;
-    const float wr = w_re[off], wi = w_im[off];
-    const float top = ri == 0 ? wr : -wi, bot = ri == 0 ? wi : wr;
-    if (fold) {
-        const float* z = fold + (size_t)co * 6;
-        return ro == 0 ? z[0] * top + z[1] * bot : z[2] * top + z[3] * bot;
-    }
-    return ro == 0 ? top : bot;
-}
 
 // out[mt][g = chunk*10 + tap][split][lane] (uint4 = 8 bf16): lane l holds row mt*32 + (l&31), channels
 // 16*chunk + 8*(l>>5) + 0..7 of tap (kt = tap/5, kf = tap%5: time-tap-major)

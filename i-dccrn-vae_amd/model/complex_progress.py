@@ -79,6 +79,7 @@ class _ComplexConvBase(nn.Module):
         self._cfg = (_pair(kernel_size), _pair(stride), _pair(padding), _pair(dilation), groups, bias, _pair(output_padding))
         self._cache = _PackCache()
         self._cache_bf16 = _PackCache()
+        self._cache_c1 = _PackCache()
 
     @property
     def _re(self):
@@ -116,6 +117,12 @@ class _ComplexConvBase(nn.Module):
         wfrag, bias = self.packed(fold, cin_used)
         wbf = None
         c1 = skip.C if skip is not None else 0
+        if (ops.PRECISION == "bf16x3" and self._transposed and self._causal and self.out_channel == 1 and stats is None
+                and skip_div == 1 and x.C % 8 == 0 and c1 % 8 == 0):
+            re, im = self._re, self._im
+            wc1 = self._cache_c1.get((re.weight, im.weight, fold), cin_used, lambda: ops.pack_ctconv_c1(
+                re.weight.detach(), im.weight.detach(), fold, cin_used))
+            return ops.ctconv_c1(x, wc1, bias, slope=slope, skip=skip)
         if ops.PRECISION == "bf16x3" and ops.bf16_supported(self._transposed, x.C, c1, skip_div, self.out_channel):
             wbf = self.packed_bf16(fold, cin_used)
         return ops.cconv2d(x, wfrag, bias, self.out_channel, transposed=self._transposed, causal=self._causal,

@@ -148,6 +148,34 @@ def pack_cconv_bf16(w_re, w_im, fold, cin_used: Optional[int] = None, transposed
     return wfrag
 
 
+def pack_ctconv_c1(w_re, w_im, fold, cin_used: Optional[int] = None):
+    """Split-bf16 fragments for the Cout = 1 transposed conv (idv_ctconv_c1_bf16x3_fwd)."""
+    cin_total = w_re.shape[0]
+    cin_used = cin_total if cin_used is None else cin_used
+    L.lib().idv_ctconv_c1_wfrag_bytes.restype = L._L
+    wfrag = torch.empty(int(L.lib().idv_ctconv_c1_wfrag_bytes(i(cin_used))), dtype=torch.uint8, device=w_re.device)
+    call("idv_pack_ctconv_c1_bf16", p(w_re.contiguous()), p(w_im.contiguous()), p(fold), i(cin_total), i(cin_used), p(wfrag),
+         stream_ptr())
+    return wfrag
+
+
+def ctconv_c1(x: Planar, wfrag_c1, bias, *, slope=None, skip: Optional[Planar] = None) -> Planar:
+    """Causal / non-causal transposed conv with one output channel on the split-bf16 path."""
+    out = Planar.empty(1, 2 * x.F - 1, x.B, x.T, x.Tp, x.buf.device)
+    c1 = skip.C if skip is not None else 0
+    if LAUNCH_LOG is not None:
+        macs = 4 * (x.C + c1) * 10 * x.B * x.T * x.F
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    call("idv_ctconv_c1_bf16x3_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
+         i(skip.Jp if skip is not None else 0), p(wfrag_c1), p(bias), p(slope), out.ptr(), i(x.F), i(x.B), i(x.Tp), i(x.Jp),
+         i(x.T), stream_ptr())
+    if LAUNCH_LOG is not None:
+        ev1.record()
+        LAUNCH_LOG.append((-99, macs, ev0, ev1))
+    return out
+
+
 def pack_pw(w, bias):
     M, K = w.shape
     mt = mtiles_alloc(M)

@@ -96,6 +96,17 @@ int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, int C1, int
                            const float* bias, const float* prelu_slope, float* out, double* stats, int transposed,
                            int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
 
+/* Last decoder block (Cout = 1): transposed conv re-associated so that the five frequency taps sit in the MFMA
+ * M dimension (10 rows instead of 2), taps combined in the epilogue; split-bf16 arithmetic, eval mode only
+ * (folded BN + PReLU; train-mode statistics use idv_cconv2d_fwd).  Same reference lines as idv_cconv2d_fwd.
+ * Needs C0 % 8 == 0, C1 % 8 == 0, no repeated skips.  bias: bias_out of idv_pack_cconv (2 values used). */
+long long idv_ctconv_c1_wfrag_bytes(int cin_used);
+int idv_pack_ctconv_c1_bf16(const float* w_re, const float* w_im, const float* fold, int Cin_total, int Cin_used,
+                            void* wfrag, void* stream);
+int idv_ctconv_c1_bf16x3_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, const void* wfrag,
+                             const float* bias, const float* prelu_slope, float* out, int Fin, int B, int Tp, int Jp,
+                             int t_valid_out, void* stream);
+
 /* out[m][j] = bias[m] + sum_k w[m][k] x[k][j] over K planes of stride Jp: ComplexDense.forward
  * (complex_progress.py:83-89, one call per real/imag linear), the LSTM input projections, and the
  * DFT / inverse DFT.  swap=1 writes out[((tp-1)*B + b)*ldo + m] instead of planar rows. */

@@ -439,3 +439,34 @@ def test_clstm_bf16x3(ops, T, B, I):
     got32 = ops.clstm(xp, p0, p1, H).channel_slice(0, H).cpu().permute(1, 0, 2, 3)
     e16, e32 = relerr(got16, want), relerr(got32, want)
     assert e32 < TOL and e16 < 1e-4, (e16, e32)
+
+
+@pytest.mark.parametrize("cin,skip_c,F,T,B", [(16, 16, 17, 70, 2), (32, 32, 129, 40, 3), (8, 0, 9, 130, 2), (24, 8, 33, 33, 1)])
+def test_ctconv_c1_bf16x3(ops, cin, skip_c, F, T, B):
+    """Cout = 1 transposed conv with the frequency taps re-associated into the MFMA M dimension (last decoder block)."""
+    g = torch.Generator().manual_seed(21)
+    dev = "cuda"
+    cin_tot = cin + skip_c
+    x = torch.randn(B, cin, F, T, 2, generator=g)
+    wr, wi = torch.randn(cin_tot, 1, 5, 2, generator=g) * 0.1, torch.randn(cin_tot, 1, 5, 2, generator=g) * 0.1
+    br, bi = torch.randn(1, generator=g), torch.randn(1, generator=g)
+    xin, sk = x, None
+    if skip_c:
+        sk = torch.randn(B, skip_c, F, T, 2, generator=g)
+        xin = torch.cat([x, sk], dim=1)
+    want = O.complex_conv_transpose2d(xin.double(), wr.double(), br.double(), wi.double(), bi.double(), (2, 1), (2, 0), True).float()
+    mom = torch.tensor([[0.05], [-0.02], [0.8], [0.1], [1.2]])
+    gam = [torch.tensor([1.1]), torch.tensor([0.3]), torch.tensor([0.9])]
+    bet = [torch.tensor([0.05]), torch.tensor([-0.1])]
+    want = O.prelu(O.cbn_whiten_affine(want, mom[0], mom[1], mom[2], mom[3], mom[4], gam[0], gam[1], gam[2], bet[0], bet[1]),
+                   torch.tensor(0.25))
+    fold = ops.cbn_fold(mom.to(dev), *[t.to(dev) for t in gam], *[t.to(dev) for t in bet])
+    xp = ops.Planar.from_tensor5(x.to(dev), T + 2)
+    skp = ops.Planar.from_tensor5(sk.to(dev), T + 2) if sk is not None else None
+    _, bias = ops.pack_cconv(wr.to(dev), wi.to(dev), br.to(dev), bi.to(dev), fold, transposed=True)
+    wc1 = ops.pack_ctconv_c1(wr.to(dev), wi.to(dev), fold)
+    y = ops.ctconv_c1(xp, wc1, bias, slope=torch.tensor([0.25], device=dev), skip=skp)
+    got = y.tensor5().cpu()
+    assert got.shape == want.shape
+    assert relerr(got, want) < 2e-4
+    assert float(y.planes()[..., 0].abs().max()) == 0.0 and float(y.planes()[..., y.T + 1:].abs().max()) == 0.0
