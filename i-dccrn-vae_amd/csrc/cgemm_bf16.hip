@@ -10,11 +10,12 @@
 // 5-tap register ring (4 taps of prefetch distance).
 #include "bf16_common.hpp"
 #include "../../include/idccrn_hip.h"
+#include <stdlib.h>
 
 namespace {
 
 template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS>
-__global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_bf16_kernel(const CgemmArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1) ? 2 : 1) void cgemm_bf16_kernel(const CgemmArgs a) {
     using G = CgemmGeom<MODE, FO_T>;
     constexpr int NT = WM * WN * 64;
     constexpr int KF = 5, FR = G::FR, ROWS = G::ROWS;
@@ -366,7 +367,7 @@ extern "C" int idv_cconv_bf16_config(int transposed, int Cout, int Fin) {
     const bool fo5 = waste(rows, 5) <= waste(rows, 3);
     const bool wide = 2 * Cout >= 128;
     const int mode = transposed ? 1 : 0;
-    if (wide) return mode * 10000 + (fo5 ? 4151 : 4132);
+    if (wide) return mode * 10000 + (fo5 ? 4151 : (transposed ? 4132 : 4131));
     return mode * 10000 + (fo5 ? 2251 : 2231);
 }
 
@@ -404,6 +405,10 @@ extern "C" int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, 
     const int rows = transposed ? Fin : a.Fout;
     const bool fo5 = waste(rows, 5) <= waste(rows, 3);
     const bool wide = a.M >= 128;                            // 4 row tiles per workgroup when the layer has them
+    // measured (B = 64): the conv with 3 row tiles runs best at 2 waves/SIMD with 32-column tiles (JC_W = 1),
+    // the transposed conv (12 accumulator tiles) at 1 wave/SIMD with 64-column tiles
+    if (wide && !fo5 && !transposed)
+        return stats ? launch_bf16<IDV_CONV, 4, 1, 3, 1, true>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 1, false>(a, st);
 #define IDV_BF16_DISPATCH(MODE)                                                                              \
     if (stats) {                                                                                             \
         if (wide) return fo5 ? launch_bf16<MODE, 4, 1, 5, 1, true>(a, st) : launch_bf16<MODE, 4, 1, 3, 2, true>(a, st);   \
