@@ -176,11 +176,18 @@ def main():
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)                 # rehearsal of N ranks on fewer GPUs (IDV_BENCH_BACKEND=gloo) shares devices
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("IDV_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     ops = importlib.import_module("i-dccrn-vae_amd").ops
     ops.set_precision(args.precision)
@@ -212,7 +219,8 @@ def main():
     log(f"timed {args.steps} steps in {elapsed:.3f} s")
 
     dt = importlib.import_module("i-dccrn-vae_amd.utils.dist_timing")
-    value, elapsed = dt.job_throughput(elapsed, float(utt_per_step * args.steps), device)
+    red_dev = device if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
+    value, elapsed = dt.job_throughput(elapsed, float(utt_per_step * args.steps), red_dev)
 
     # dominant kernel: group conv launches by kernel instantiation, HIP-event durations on the launch stream
     def kernel_name(cfg_id):
