@@ -230,8 +230,8 @@ def main():
             d = str(cfg_id)
             mode, t = (1 if len(d) == 7 else 0), d[-6:]
             return f"void cgemm_kernel<{mode}, {t[0]}, {t[1]}, {t[2]}, {t[3]}, {t[4]}, {t[5]}, false, false, true>(CgemmArgs)"
-        d = str(-cfg_id - 100000).rjust(5, "0")
-        return f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false>(CgemmArgs)"
+        d = str(-cfg_id - 1000000).rjust(6, "0")
+        return f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false, {d[5]}>(CgemmArgs)"
 
     groups = {}
     for cfg_id, macs, e0, e1 in launches:

@@ -14,8 +14,8 @@
 
 namespace {
 
-template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS>
-__global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1) ? 2 : 1) void cgemm_bf16_kernel(const CgemmArgs a) {
+template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS, int MT_W = 1>
+__global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) ? 2 : 1) void cgemm_bf16_kernel(const CgemmArgs a) {
     using G = CgemmGeom<MODE, FO_T>;
     constexpr int NT = WM * WN * 64;
     constexpr int KF = 5, FR = G::FR, ROWS = G::ROWS;
@@ -43,18 +43,20 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1) ? 2 : 1) void
     if (tile >= a.jtiles * FTn) return;
     const int jt = tile / FTn, ft = tile - jt * FTn;
     const int j0 = jt * JT;
-    const int mt0 = mblk * WM + wm;                          // this wave's 32-row tile
+    const int mt0 = (mblk * WM + wm) * MT_W;                 // this wave's first 32-row tile
     const int fo0 = ft * FO_T;
     const int fbase = (MODE == IDV_CONV) ? 2 * fo0 - 2 : fo0 - 1;
 
     const int CC = 2 * (a.C0 + a.C1);
     const int nchunk = CC / 16;
 
-    f32x16 acc[NCOL];
+    f32x16 acc[MT_W][NCOL];
 #pragma unroll
-    for (int c = 0; c < NCOL; ++c)
+    for (int i = 0; i < MT_W; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        for (int c = 0; c < NCOL; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
 
     // ---- staging ------------------------------------------------------------------------------------
     f32x4 stg[NLD][8];
@@ -142,14 +144,16 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1) ? 2 : 1) void
     // frequency taps of one time tap.  The phase after the current one is prefetched into the other half.
     const int NPH = nchunk * 2;
     const uint4* wstream = (const uint4*)a.wfrag + (size_t)mt0 * NPH * 5 * 128 + lane;
-    uint4 a_hi[2][5], a_lo[2][5];
-    auto load_a = [&](int ph, uint4 (&dh)[5], uint4 (&dl)[5]) {
+    uint4 a_hi[2][5][MT_W], a_lo[2][5][MT_W];
+    auto load_a = [&](int ph, uint4 (&dh)[5][MT_W], uint4 (&dl)[5][MT_W]) {
         const int pp = ph < NPH ? ph : NPH - 1;            // past the end: harmless re-read
 #pragma unroll
-        for (int kf = 0; kf < 5; ++kf) {
-            dh[kf] = wstream[(size_t)(pp * 5 + kf) * 128];
-            dl[kf] = wstream[(size_t)(pp * 5 + kf) * 128 + 64];
-        }
+        for (int kf = 0; kf < 5; ++kf)
+#pragma unroll
+            for (int i = 0; i < MT_W; ++i) {
+                dh[kf][i] = wstream[((size_t)i * NPH * 5 + pp * 5 + kf) * 128];
+                dl[kf][i] = wstream[((size_t)i * NPH * 5 + pp * 5 + kf) * 128 + 64];
+            }
     };
 
     // ---- activation fragments: one LDS row (fr) serves every (output row, freq tap) pair that reads it ----
@@ -173,10 +177,12 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1) ? 2 : 1) void
     load_a(0, a_hi[0], a_lo[0]);
     stage_store(smem16);
 #pragma unroll
-    for (int kf = 0; kf < 5; ++kf) {
-        asm volatile("" : "+v"(a_hi[0][kf].x), "+v"(a_hi[0][kf].y), "+v"(a_hi[0][kf].z), "+v"(a_hi[0][kf].w));
-        asm volatile("" : "+v"(a_lo[0][kf].x), "+v"(a_lo[0][kf].y), "+v"(a_lo[0][kf].z), "+v"(a_lo[0][kf].w));
-    }
+    for (int kf = 0; kf < 5; ++kf)
+#pragma unroll
+        for (int i = 0; i < MT_W; ++i) {
+            asm volatile("" : "+v"(a_hi[0][kf][i].x), "+v"(a_hi[0][kf][i].y), "+v"(a_hi[0][kf][i].z), "+v"(a_hi[0][kf][i].w));
+            asm volatile("" : "+v"(a_lo[0][kf][i].x), "+v"(a_lo[0][kf][i].y), "+v"(a_lo[0][kf][i].z), "+v"(a_lo[0][kf][i].w));
+        }
     __syncthreads();
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -207,17 +213,20 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1) ? 2 : 1) void
                             frr = (rt >> 1) + 2 - (kf >> 1);
                         }
                         if (frr != fr) continue;
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi[kt][kf]);
-                        const bf16x8 al = __builtin_bit_cast(bf16x8, a_lo[kt][kf]);
 #pragma unroll
-                        for (int jc = 0; jc < JC_W; ++jc) {
-                            const bf16x8 bh = __builtin_bit_cast(bf16x8, b_h[jc]);
-                            const bf16x8 bl = __builtin_bit_cast(bf16x8, b_l[jc]);
-                            f32x16 c = acc[rt * JC_W + jc];
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-                            acc[rt * JC_W + jc] = c;
+                        for (int i = 0; i < MT_W; ++i) {
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi[kt][kf][i]);
+                            const bf16x8 al = __builtin_bit_cast(bf16x8, a_lo[kt][kf][i]);
+#pragma unroll
+                            for (int jc = 0; jc < JC_W; ++jc) {
+                                const bf16x8 bh = __builtin_bit_cast(bf16x8, b_h[jc]);
+                                const bf16x8 bl = __builtin_bit_cast(bf16x8, b_l[jc]);
+                                f32x16 c = acc[i][rt * JC_W + jc];
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                                acc[i][rt * JC_W + jc] = c;
+                            }
                         }
                     }
                 }
@@ -233,8 +242,9 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1) ? 2 : 1) void
     // ------------------------------------------------------------------ epilogue (as cgemm.hpp, !SWAP)
     const float slope = a.slope ? *a.slope : 1.0f;
     const bool has_act = a.slope != nullptr;
-    {
-        const int mt = mt0;
+#pragma unroll
+    for (int ei = 0; ei < MT_W; ++ei) {
+        const int mt = mt0 + ei;
         float bia[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) bia[r] = a.bias[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1) ? 2 : 1) void
             for (int rt = 0; rt < ROWS; ++rt) {
                 const int fo = (MODE == IDV_TCONV) ? 2 * (fo0 + (rt >> 1)) + (rt & 1) : fo0 + rt;
                 if (fo >= a.Fout) continue;
-                const f32x16 v = acc[rt * JC_W + jc];
+                const f32x16 v = acc[ei][rt * JC_W + jc];
                 float y[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1) ? 2 : 1) void
     }
 }
 
-template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS>
+template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS, int MT_W = 1>
 int launch_bf16(const CgemmArgs& a, hipStream_t st) {
     using G = CgemmGeom<MODE, FO_T>;
     constexpr int JT = 32 * JC_W * WN;
@@ -305,11 +315,11 @@ int launch_bf16(const CgemmArgs& a, hipStream_t st) {
     CgemmArgs b = a;
     b.jtiles = (a.J + JT - 1) / JT;
     b.ftiles = (rows + FO_T - 1) / FO_T;
-    b.mblocks = ((a.M + 31) / 32 + WM - 1) / WM;
+    b.mblocks = ((a.M + 31) / 32 + WM * MT_W - 1) / (WM * MT_W);
     const long long tiles = (long long)b.jtiles * b.ftiles;
     const long long nblk = ((tiles + 7) / 8) * 8 * b.mblocks;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = cgemm_bf16_kernel<MODE, WM, WN, FO_T, JC_W, STATS>;
+    auto k = cgemm_bf16_kernel<MODE, WM, WN, FO_T, JC_W, STATS, MT_W>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return IDV_ELAUNCH;
@@ -363,12 +373,14 @@ extern "C" int idv_cconv_bf16_supported(int transposed, int C0, int C1, int x1_d
 
 // template arguments <MODE, WM, WN, FO_T, JC_W> of the cgemm_bf16_kernel instantiation a layer shape uses, as digits
 extern "C" int idv_cconv_bf16_config(int transposed, int Cout, int Fin) {
+    // digits <MODE, WM, WN, FO_T, JC_W, MT_W> of the instantiation the eval-mode (no statistics) launch uses
     const int rows = transposed ? Fin : (Fin - 1) / 2 + 1;
     const bool fo5 = waste(rows, 5) <= waste(rows, 3);
     const bool wide = 2 * Cout >= 128;
     const int mode = transposed ? 1 : 0;
-    if (wide) return mode * 10000 + (fo5 ? 4151 : (transposed ? 4132 : 4131));
-    return mode * 10000 + (fo5 ? 2251 : 2231);
+    if (!transposed && 2 * Cout >= 256) return fo5 ? 41512 : 41322;
+    if (wide) return mode * 100000 + (fo5 ? 41511 : (transposed ? 41321 : 41311));
+    return mode * 100000 + (fo5 ? 22511 : 22311);
 }
 
 extern "C" int idv_pack_cconv_bf16(const float* w_re, const float* w_im, const float* fold, int Cout, int Cin_total,
@@ -407,6 +419,10 @@ extern "C" int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, 
     const bool wide = a.M >= 128;                            // 4 row tiles per workgroup when the layer has them
     // measured (B = 64): the conv with 3 row tiles runs best at 2 waves/SIMD with 32-column tiles (JC_W = 1),
     // the transposed conv (12 accumulator tiles) at 1 wave/SIMD with 64-column tiles
+    // conv layers with >= 256 rows: two row tiles per wave (256-row workgroups) halve the staging per MFMA
+    // (measured -10 % on enc5, -1.5 % on enc2..4; the transposed conv gets slower or spills, so it keeps one)
+    if (a.M >= 256 && !stats && !transposed)
+        return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, false, 2>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 2, false, 2>(a, st);
     if (wide && !fo5 && !transposed)
         return stats ? launch_bf16<IDV_CONV, 4, 1, 3, 1, true>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 1, false>(a, st);
 #define IDV_BF16_DISPATCH(MODE)                                                                              \

@@ -216,7 +216,7 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
         ev0.record()
     if wfrag_bf16 is not None:
         if LAUNCH_LOG is not None:
-            cfg = -(100000 + L.lib().idv_cconv_bf16_config(i(1 if transposed else 0), i(cout), i(x.F)))
+            cfg = -(1000000 + L.lib().idv_cconv_bf16_config(i(1 if transposed else 0), i(cout), i(x.F)))
         call("idv_cconv2d_bf16x3_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
              i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag_bf16), p(bias), p(slope), out.ptr(), p(stats),
              i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())

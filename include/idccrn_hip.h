@@ -89,7 +89,7 @@ int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, i
  * bias: the fp32 bias vector produced by idv_pack_cconv. */
 long long idv_cconv_bf16_wfrag_bytes(int Cout, int cin_used);
 int idv_cconv_bf16_supported(int transposed, int C0, int C1, int x1_div, int Cout);
-int idv_cconv_bf16_config(int transposed, int Cout, int Fin);   /* <MODE, WM, WN, FO_T, JC_W> as digits, for profiles */
+int idv_cconv_bf16_config(int transposed, int Cout, int Fin);   /* <MODE, WM, WN, FO_T, JC_W, MT_W> as digits, for profiles */
 int idv_pack_cconv_bf16(const float* w_re, const float* w_im, const float* fold, int Cout, int Cin_total, int Cin_used,
                         int transposed, void* wfrag, void* stream);
 int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const void* wfrag_bf16,
