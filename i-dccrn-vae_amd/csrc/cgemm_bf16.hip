@@ -23,10 +23,15 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
     constexpr int PS = JT + 8;                       // columns j0-4 .. j0+JT+3
     constexpr int PS4 = PS / 4;
     constexpr int NCOL = ROWS * JC_W;
-    constexpr int IMG = FR * PS * 16;                // bf16 elements of one image (hi or lo)
+    constexpr int FRP_ = ((((FR * ((JT + 8) / 4) * 2) + NT - 1) / NT) * NT + ((JT + 8) / 4) * 2 - 1) / (((JT + 8) / 4) * 2);
+    constexpr int IMG = FRP_ * PS * 16;              // bf16 elements of one image (hi or lo), padded rows included
     constexpr int BUF = 2 * IMG;                     // hi + lo
     constexpr int NTASK = FR * PS4 * 2;              // (row, 4-column group, channel octet)
     constexpr int NLD = (NTASK + NT - 1) / NT;
+    // the LDS image is padded to FRP rows so that all NLD*NT staging slots are distinct in-bounds tasks: the
+    // staging code then has no divergent branch (one basic block -> it interleaves with the MFMAs)
+    constexpr int FRP = (NLD * NT + PS4 * 2 - 1) / (PS4 * 2);
+    static_assert(FRP == FRP_, "padded row count");
 
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
 
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
         const int fr = rest / PS4, c4 = rest - fr * PS4;
         const int fi = fbase + fr;
         const int jv = j0 - 4 + 4 * c4;
-        const bool rowok = (e < NTASK) && (fi >= 0) && (fi < a.Fin);
+        const bool rowok = (fr < FR) && (fi >= 0) && (fi < a.Fin);
         unsigned bits = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -107,35 +112,27 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
             const int e = tid + i * NT;
             const int oct = e & 1, rest = e >> 1;
             const unsigned bits = (okbits >> (4 * i)) & 15u;
-            if (e < NTASK) {
-                // edge tasks (freq padding, batch head / tail) zero their invalid columns; interior tasks skip it
-                if (bits != 15u) {
 #pragma unroll
-                    for (int p = 0; p < 8; ++p)
+            for (int p = 0; p < 8; ++p)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) stg[i][p][q] = ((bits >> q) & 1u) ? stg[i][p][q] : 0.f;
+                for (int q = 0; q < 4; ++q) stg[i][p][q] = ((bits >> q) & 1u) ? stg[i][p][q] : 0.f;
+            const int frw = rest / PS4, c4w = rest - frw * PS4;
+            // image[fr][octet][column][8 channels]: lanes of one MFMA operand half read consecutive 16-byte slots
+            unsigned short* d0 = dst + ((size_t)((frw * 2 + oct) * PS + 4 * c4w) * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float x0 = stg[i][2 * w][q], x1 = stg[i][2 * w + 1][q];
+                    // hi = truncation to bf16 (one AND), lo = round-to-nearest of the exact remainder
+                    const unsigned u0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u;
+                    const unsigned u1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
+                    hw[w] = (u0 >> 16) | u1;
+                    lw[w] = pack_bf16(x0 - __builtin_bit_cast(float, u0), x1 - __builtin_bit_cast(float, u1));
                 }
-                const int frw = rest / PS4, c4w = rest - frw * PS4;
-                // image[fr][octet][column][8 channels]: lanes of one MFMA operand half read consecutive 16-byte slots
-                unsigned short* d0 = dst + ((size_t)((frw * 2 + oct) * PS + 4 * c4w) * 8);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint4 hi, lo;
-                    unsigned hw[4], lw[4];
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const float x0 = stg[i][2 * w][q], x1 = stg[i][2 * w + 1][q];
-                        // hi = truncation to bf16 (one AND), lo = round-to-nearest of the exact remainder
-                        const unsigned u0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u;
-                        const unsigned u1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
-                        hw[w] = (u0 >> 16) | u1;
-                        lw[w] = pack_bf16(x0 - __builtin_bit_cast(float, u0), x1 - __builtin_bit_cast(float, u1));
-                    }
-                    hi = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-                    lo = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-                    *(uint4*)(d0 + q * 8) = hi;
-                    *(uint4*)(d0 + q * 8 + IMG) = lo;
-                }
+                *(uint4*)(d0 + q * 8) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                *(uint4*)(d0 + q * 8 + IMG) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
             }
         }
     };
@@ -309,7 +306,10 @@ template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS, int MT_W = 1
 int launch_bf16(const CgemmArgs& a, hipStream_t st) {
     using G = CgemmGeom<MODE, FO_T>;
     constexpr int JT = 32 * JC_W * WN;
-    constexpr size_t smem = (size_t)2 * 2 * G::FR * (JT + 8) * 16 * sizeof(unsigned short);
+    constexpr int PS4L = (JT + 8) / 4;
+    constexpr int NTL = WM * WN * 64;
+    constexpr int FRPL = ((((G::FR * PS4L * 2) + NTL - 1) / NTL) * NTL + PS4L * 2 - 1) / (PS4L * 2);
+    constexpr size_t smem = (size_t)2 * 2 * FRPL * (JT + 8) * 16 * sizeof(unsigned short);
     static_assert(smem <= 160 * 1024, "LDS budget");
     const int rows = (MODE == IDV_TCONV) ? a.Fin : a.Fout;
     CgemmArgs b = a;
