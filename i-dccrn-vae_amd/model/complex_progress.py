@@ -56,6 +56,8 @@ class _PackCache:
         if key != self.key:
             self.val = build()
             self.key = key
+            # the pack kernels ran on the current stream; later users may be on another one (sub-batch streams)
+            torch.cuda.current_stream().synchronize()
         return self.val
 
 

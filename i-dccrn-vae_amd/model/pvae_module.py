@@ -29,6 +29,7 @@ def dft_plan(n_fft, win, hop, T, device) -> ops.DftPlan:
     key = (n_fft, win, hop, T, str(device))
     if key not in _PLANS:
         _PLANS[key] = ops.DftPlan(n_fft, win, hop, T, device)
+        torch.cuda.current_stream(device).synchronize()       # built once; users may sit on other streams
     return _PLANS[key]
 
 
@@ -184,8 +185,10 @@ class standard_DCCRN(nn.Module):
         self.linear = ComplexConv2d(in_channel=1, out_channel=1, kernel_size=1, stride=1)   # unused, kept for state_dict parity
         self.detect_anormal = True
 
-    def forward_planar(self, x: Planar, train: bool = True) -> Planar:
+    def forward_planar(self, x: Planar, train: bool = True, on_encoded=None) -> Planar:
         skips = _run_encoders(self.encoders, x, train)
+        if on_encoded is not None:
+            on_encoded()
         top = skips[-1]
         lat = top
         for lstm in self.lstms:
@@ -238,9 +241,37 @@ class DCCRN_(nn.Module):
         self.datanorm = self.data_mean is not None and self.data_std is not None
 
     def forward(self, signal, train=True):
+        # Eval is per-utterance independent (folded BN): run sub-batches on separate HIP streams so one sub-batch's
+        # 16-CU LSTM recurrence and kernel tails overlap the other's conv GEMMs.  Train mode needs whole-batch
+        # CBN statistics and stays on one stream.
+        n = 1 if train else ops.stream_split(signal.shape[0])
+        if n == 1:
+            return self._forward_one(signal, train)
+        main = torch.cuda.current_stream(signal.device)
+        outs = []
+        streams = ops.side_streams(n, signal.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        encoded = None                                            # staggered: part k+1 starts when part k enters its LSTM
+        for part, st in zip(signal.tensor_split(n), streams):
+            st.wait_event(ready)
+            if encoded is not None and ops.STREAM_STAGGER and part.shape[0] < ops.STREAM_STAGGER_BELOW:
+                st.wait_event(encoded)
+            encoded = torch.cuda.Event()
+            with torch.cuda.stream(st):
+                outs.append(self._forward_one(part, False, encoded.record) + (self.std_DCCRN.latent,))
+        for st in streams:                                        # join only after every part is enqueued
+            main.wait_stream(st)
+        clean, predict, latent = (torch.cat([o[k] for o in outs]) for k in range(3))
+        # no record_stream: the parts are released to their own stream's pool, and that stream's next use starts
+        # with wait_event(ready) above, i.e. after these concatenations have run
+        self.std_DCCRN.latent = latent
+        return clean, predict
+
+    def _forward_one(self, signal, train, on_encoded=None):
         X = self.stft.planar(signal)
         net_in = _apply_datanorm(X, self.data_mean, self.data_std) if self.datanorm else X
-        out = self.std_DCCRN.forward_planar(net_in, train=train)
+        out = self.std_DCCRN.forward_planar(net_in, train=train, on_encoded=on_encoded)
         pred, predict = _predict_outputs(self, out, net_in, self.recon_type)
         if self.datanorm:
             pr = torch.view_as_real(predict)

@@ -192,6 +192,28 @@ def pack_pw(w, bias):
 # bench.py uses it to time the dominant kernel with events on the launching stream.
 LAUNCH_LOG = None
 
+# Eval-mode sub-batch pipelining (model/pvae_module.py DCCRN_.forward): number of HIP streams a batch is split over.
+STREAM_SPLIT = int(os.environ.get("IDV_STREAM_SPLIT", "2"))
+STREAM_STAGGER = os.environ.get("IDV_STREAM_STAGGER", "1") != "0"   # part k+1 starts when part k reaches its LSTM
+STREAM_STAGGER_BELOW = 64                        # measured: staggering pays for parts of < 64 utterances (B=64: +4.5 %), not above
+STREAM_SPLIT_MIN_BATCH = 16                      # per-stream utterances below which launch overhead dominates
+_SIDE_STREAMS = {}
+
+
+def stream_split(batch: int) -> int:
+    n = max(1, STREAM_SPLIT)
+    while n > 1 and batch < n * STREAM_SPLIT_MIN_BATCH:
+        n -= 1
+    return n
+
+
+def side_streams(n: int, device):
+    key = (torch.device(device).index or 0)
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
 
 def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True, slope=None, skip: Optional[Planar] = None,
             skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None,

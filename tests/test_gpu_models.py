@@ -93,6 +93,36 @@ def test_dccrn_vs_oracle_other_length(pm):
     assert relerr(torch.view_as_real(p2).cpu(), O.stft(o_c2, NFFT, HOP, WIN)) < WAVE_TOL
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_dccrn_stream_split_is_bit_exact(pm, precision):
+    """Eval sub-batches on separate HIP streams (DCCRN_.forward) vs one stream: per-utterance results identical,
+    uneven split included; a second call reuses the per-stream pools."""
+    ops = pm.ops
+    np_ = O.net_params(True, 4)
+    m = load_synth(pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None), 5)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(7, 4000, generator=g) * 0.1).cuda()
+    keep = (ops.STREAM_SPLIT, ops.STREAM_SPLIT_MIN_BATCH, ops.PRECISION)
+    try:
+        ops.set_precision(precision)
+        ops.STREAM_SPLIT_MIN_BATCH = 1
+        ops.STREAM_SPLIT = 1
+        c1, p1 = m(x, train=False)
+        lat1 = m.std_DCCRN.latent.clone()
+        for n in (2, 3, 2):
+            ops.STREAM_SPLIT = n
+            assert ops.stream_split(7) == n
+            c2, p2 = m(x, train=False)
+            torch.cuda.synchronize()
+            assert torch.equal(c1, c2) and torch.equal(torch.view_as_real(p1), torch.view_as_real(p2))
+            assert torch.equal(lat1, m.std_DCCRN.latent)
+        ops.STREAM_SPLIT_MIN_BATCH = 16
+        assert ops.stream_split(7) == 1 and ops.stream_split(32) == 2 and ops.stream_split(31) == 1
+    finally:
+        ops.STREAM_SPLIT, ops.STREAM_SPLIT_MIN_BATCH = keep[0], keep[1]
+        ops.set_precision(keep[2])
+
+
 @pytest.mark.parametrize("tag", ["mini_eval", "mini_train"])
 def test_cvae_golden(pm, losses, golden, tag):
     d = golden("vae_cvae_" + tag)
