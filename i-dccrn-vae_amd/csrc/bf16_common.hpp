@@ -4,6 +4,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     bf16x2 v = {(__bf16)a, (__bf16)b};

@@ -47,7 +47,14 @@ struct CgemmArgs {
     int ldo;              // SWAP: row stride of out; rows are ordered (tp-1)*B + b
     int nB;               // SWAP: utterances (B)
     int jtiles, ftiles, mblocks;   // grid decomposition (filled by the launcher)
+    // split-bf16 image sources / destination (cgemm_bf16.hip, cgemm_c1.hip); x0 / x1 then point at image data
+    long long lo_off0, lo_off1;    // hi -> lo plane distance of the x0 / x1 image, in 16-byte slots
+    void* out_img;                 // optional image destination (besides or instead of `out`)
+    long long out_lo_off;          // its hi -> lo distance, in bf16 elements
 };
+// 16-byte slot, relative to the start of an image plane, that every producer of an image zeroes (both planes):
+// consumers read it for frequency rows outside [0, Fin)
+#define IDV_IMG_ZSLOT (-8)
 
 template <int MODE, int FO_T>
 struct CgemmGeom {

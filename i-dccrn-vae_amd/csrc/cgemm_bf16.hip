@@ -12,9 +12,23 @@
 #include "../../include/idccrn_hip.h"
 #include <stdlib.h>
 
+#ifndef IDV_AD
+#define IDV_AD 3
+#endif
+#ifndef IDV_IMG_DMA
+#define IDV_IMG_DMA 1
+#endif
+
 namespace {
 
-template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS, int MT_W = 1>
+// IMGIN: the sources are split-bf16 images (see idccrn_hip.h "split image"): staging is a plain 16-byte copy
+// global -> LDS in linear slot order, no conversion and no transposition.
+template <int K>
+struct IntC { static constexpr int value = K; };
+
+// AD: depth of the weight-fragment ring in phases (one phase = the 5 frequency taps of one time tap of one chunk);
+// fragments are fetched AD-1 phases ahead of their use.
+template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS, int MT_W = 1, bool IMGIN = false, int AD = 2>
 __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) ? 2 : 1) void cgemm_bf16_kernel(const CgemmArgs a) {
     using G = CgemmGeom<MODE, FO_T>;
     constexpr int NT = WM * WN * 64;
@@ -32,6 +46,10 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
     // staging code then has no divergent branch (one basic block -> it interleaves with the MFMAs)
     constexpr int FRP = (NLD * NT + PS4 * 2 - 1) / (PS4 * 2);
     static_assert(FRP == FRP_, "padded row count");
+    // image-source staging: one task = one 16-byte slot (fr, octet, column) of the LDS image, in linear order
+    constexpr int NSLOT = FR * 2 * PS;
+    constexpr int NLDI = (NSLOT + NT - 1) / NT;
+    static_assert(NLDI * NT * 8 <= IMG, "padded image holds every staging slot");
 
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
 
@@ -64,11 +82,93 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
             for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
 
     // ---- staging ------------------------------------------------------------------------------------
-    f32x4 stg[NLD][8];
+    u32x4 sth[IMGIN ? NLDI : 1], stl[IMGIN ? NLDI : 1];
+    int ioff[IMGIN ? NLDI : 1];
+    unsigned iok = 0;
+    if (IMGIN) {
+#pragma unroll
+        for (int i = 0; i < NLDI; ++i) {
+            const int t = tid + i * NT;
+            const int fr = t / (2 * PS), rem = t - fr * (2 * PS);
+            const int oct = rem / PS, col = rem - oct * PS;
+            const int fi = fbase + fr;
+            const bool ok = (fr < FR) && (fi >= 0) && (fi < a.Fin);
+            iok |= (ok ? 1u : 0u) << i;
+            // columns outside [0, J) are read as they lie (neighbouring row / slack): they only reach outputs
+            // that the epilogue forces to zero (guard columns) or drops (j >= J)
+            ioff[i] = (oct * a.Fin + fi) * a.Jp + (j0 - 4 + col);
+        }
+    }
+    auto stage_load_img = [&](int chunk) {
+        const int ci0 = chunk * 8;
+        const u32x4* xh;
+        const u32x4* xl;
+        int zoff;           // rows outside [0, Fin) read the image's zero slot (IDV_IMG_ZSLOT, both planes)
+        if (ci0 < a.C0) {
+            const int o0 = (ci0 / 4) * a.Fin * a.Jp;
+            xh = (const u32x4*)a.x0 + o0;
+            xl = xh + a.lo_off0;
+            zoff = IDV_IMG_ZSLOT - o0;
+        } else {
+            const int o1 = ((ci0 - a.C0) / 4) * a.Fin * a.Jp;
+            xh = (const u32x4*)a.x1 + o1;
+            xl = xh + a.lo_off1;
+            zoff = IDV_IMG_ZSLOT - o1;
+        }
+#pragma unroll
+        for (int i = 0; i < NLDI; ++i) {
+            const int o = ((iok >> i) & 1u) ? ioff[i] : zoff;
+            sth[i] = xh[o];
+            stl[i] = xl[o];
+        }
+    };
+    // direct global -> LDS copies (global_load_lds_dwordx4): lane l of a wave fills slot (wave*64 + i*NT + l), i.e.
+    // 1 KiB of contiguous LDS per instruction, no VGPR round trip and no ds_write
+    auto stage_dma = [&](int chunk, unsigned short* dst, int i_lo, int i_hi) {
+        const int ci0 = chunk * 8;
+        const u32x4* xh;
+        long long lo;
+        int zoff;
+        if (ci0 < a.C0) {
+            const int o0 = (ci0 / 4) * a.Fin * a.Jp;
+            xh = (const u32x4*)a.x0 + o0;
+            lo = a.lo_off0;
+            zoff = IDV_IMG_ZSLOT - o0;
+        } else {
+            const int o1 = ((ci0 - a.C0) / 4) * a.Fin * a.Jp;
+            xh = (const u32x4*)a.x1 + o1;
+            lo = a.lo_off1;
+            zoff = IDV_IMG_ZSLOT - o1;
+        }
+        // issued through inline asm: the builtin makes the compiler drain vmcnt before the next ds_read (it cannot
+        // prove the patch being read and the patch being filled are different buffers), which serialises the copy
+        typedef __attribute__((address_space(3))) unsigned short lds_u16;
+        const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u16*)(dst + (size_t)wave * 64 * 8));
+#pragma unroll
+        for (int i = 0; i < NLDI; ++i) {
+            if (i < i_lo || i >= i_hi) continue;
+            const int o = ((iok >> i) & 1u) ? ioff[i] : zoff;
+            const u32x4* gh = xh + o;
+            const u32x4* gl = gh + lo;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(gh), "s"(l0 + (unsigned)(i * NT * 16)) : "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(gl), "s"(l0 + (unsigned)(i * NT * 16 + IMG * 2)) : "memory");
+        }
+    };
+    auto stage_store_img = [&](unsigned short* dst) {
+#pragma unroll
+        for (int i = 0; i < NLDI; ++i) {
+            u32x4* d = (u32x4*)dst + (tid + i * NT);
+            d[0] = sth[i];
+            d[IMG / 8] = stl[i];
+        }
+    };
+    f32x4 stg[IMGIN ? 1 : NLD][8];
     unsigned voff[NLD];
     unsigned okbits = 0;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
+    for (int i = 0; i < (IMGIN ? 0 : NLD); ++i) {
         const int e = tid + i * NT;
         const int oct = e & 1, rest = e >> 1;
         const int fr = rest / PS4, c4 = rest - fr * PS4;
@@ -83,6 +183,7 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
         voff[i] = bits ? (unsigned)((4 * oct * a.Fin + fi) * a.Jp + jv) : 0u;
     }
     auto stage_load = [&](int chunk) {
+        if (IMGIN) { stage_load_img(chunk); return; }
         const int ci0 = chunk * 8;
         const float* base;
         unsigned ristride, chstride;
@@ -107,6 +208,7 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
         }
     };
     auto stage_store = [&](unsigned short* dst) {
+        if (IMGIN) { stage_store_img(dst); return; }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * NT;
@@ -141,16 +243,20 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
     // frequency taps of one time tap.  The phase after the current one is prefetched into the other half.
     const int NPH = nchunk * 2;
     const uint4* wstream = (const uint4*)a.wfrag + (size_t)mt0 * NPH * 5 * 128 + lane;
-    uint4 a_hi[2][5][MT_W], a_lo[2][5][MT_W];
-    auto load_a = [&](int ph, uint4 (&dh)[5][MT_W], uint4 (&dl)[5][MT_W]) {
+    static_assert(AD == 2 || AD == 3 || AD == 4, "ring depth");
+    constexpr int UNR = (AD == 2) ? 1 : (AD == 3 ? 3 : 2);      // chunks per unrolled group: 2*UNR phases = k*AD
+    uint4 a_hi[AD][5][MT_W], a_lo[AD][5][MT_W];
+    auto load_a_tap = [&](int ph, int kf, uint4 (&dh)[5][MT_W], uint4 (&dl)[5][MT_W]) {
         const int pp = ph < NPH ? ph : NPH - 1;            // past the end: harmless re-read
 #pragma unroll
-        for (int kf = 0; kf < 5; ++kf)
+        for (int i = 0; i < MT_W; ++i) {
+            dh[kf][i] = wstream[((size_t)i * NPH * 5 + pp * 5 + kf) * 128];
+            dl[kf][i] = wstream[((size_t)i * NPH * 5 + pp * 5 + kf) * 128 + 64];
+        }
+    };
+    auto load_a = [&](int ph, uint4 (&dh)[5][MT_W], uint4 (&dl)[5][MT_W]) {
 #pragma unroll
-            for (int i = 0; i < MT_W; ++i) {
-                dh[kf][i] = wstream[((size_t)i * NPH * 5 + pp * 5 + kf) * 128];
-                dl[kf][i] = wstream[((size_t)i * NPH * 5 + pp * 5 + kf) * 128 + 64];
-            }
+        for (int kf = 0; kf < 5; ++kf) load_a_tap(ph, kf, dh, dl);
     };
 
     // ---- activation fragments: one LDS row (fr) serves every (output row, freq tap) pair that reads it ----
@@ -170,9 +276,15 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
         }
     };
 
-    stage_load(0);
+    if (IMGIN && IDV_IMG_DMA) {
+        stage_dma(0, smem16, 0, NLDI);
+    } else {
+        stage_load(0);
+    }
     load_a(0, a_hi[0], a_lo[0]);
-    stage_store(smem16);
+    if (!(IMGIN && IDV_IMG_DMA)) stage_store(smem16);
+#pragma unroll
+    for (int d = 1; d < AD - 1; ++d) load_a(d, a_hi[d], a_lo[d]);
 #pragma unroll
     for (int kf = 0; kf < 5; ++kf)
 #pragma unroll
@@ -180,24 +292,35 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
             asm volatile("" : "+v"(a_hi[0][kf][i].x), "+v"(a_hi[0][kf][i].y), "+v"(a_hi[0][kf][i].z), "+v"(a_hi[0][kf][i].w));
             asm volatile("" : "+v"(a_lo[0][kf][i].x), "+v"(a_lo[0][kf][i].y), "+v"(a_lo[0][kf][i].z), "+v"(a_lo[0][kf][i].w));
         }
+    if (IMGIN && IDV_IMG_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
+    auto chunk_body = [&](const int chunk, auto kc) {
+        constexpr int KC = decltype(kc)::value;                 // chunk index modulo UNR (selects ring slots statically)
         const unsigned short* P = smem16 + (chunk & 1) * BUF;
         const int nxt = (chunk + 1 < nchunk) ? chunk + 1 : chunk;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
+            constexpr int dummy = 0; (void)dummy;
+            const int slot = (2 * KC + kt) % AD, slot_pf = (2 * KC + kt + AD - 1) % AD;
             uint4 b_h[JC_W], b_l[JC_W], n_h[JC_W], n_l[JC_W];
             load_b(P, 0, kt, b_h, b_l);
 #pragma unroll
             for (int fr = 0; fr < FR; ++fr) {
                 if (fr + 1 < FR) load_b(P, fr + 1, kt, n_h, n_l);
                 __builtin_amdgcn_sched_barrier(0);
-                if (fr == 0) {
-                    load_a(chunk * 2 + kt + 1, a_hi[kt ^ 1], a_lo[kt ^ 1]);
+                if (IMGIN && IDV_IMG_DMA) {
+                    // vector-memory instructions are spread over the frequency rows of the phase: a burst of 30 of
+                    // them per wave right after the barrier fills the CU's single address path and blocks the MFMA
+                    // issue behind it (measured: the kernel time followed the count of these instructions, not where
+                    // their data came from).  Time tap 0 carries the patch copy, both carry one weight tap per row.
+                    if (kt == 0) stage_dma(nxt, smem16 + ((chunk + 1) & 1) * BUF, (fr * NLDI) / FR, ((fr + 1) * NLDI) / FR);
+                    if (fr < 5) load_a_tap(chunk * 2 + kt + AD - 1, fr, a_hi[slot_pf], a_lo[slot_pf]);
+                } else if (fr == 0) {
+                    load_a(chunk * 2 + kt + AD - 1, a_hi[slot_pf], a_lo[slot_pf]);
                     if (kt == 0) stage_load(nxt);
                 }
-                if (kt == 1 && fr == FR / 2) stage_store(smem16 + ((chunk + 1) & 1) * BUF);
+                if (!(IMGIN && IDV_IMG_DMA) && kt == 1 && fr == FR / 2) stage_store(smem16 + ((chunk + 1) & 1) * BUF);
 #pragma unroll
                 for (int rt = 0; rt < ROWS; ++rt) {
 #pragma unroll
@@ -212,8 +335,8 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
                         if (frr != fr) continue;
 #pragma unroll
                         for (int i = 0; i < MT_W; ++i) {
-                            const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi[kt][kf][i]);
-                            const bf16x8 al = __builtin_bit_cast(bf16x8, a_lo[kt][kf][i]);
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi[slot][kf][i]);
+                            const bf16x8 al = __builtin_bit_cast(bf16x8, a_lo[slot][kf][i]);
 #pragma unroll
                             for (int jc = 0; jc < JC_W; ++jc) {
                                 const bf16x8 bh = __builtin_bit_cast(bf16x8, b_h[jc]);
@@ -233,10 +356,34 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
                 }
             }
         }
+        // the DMA of the next patch must have landed before anyone reads it; vmcnt retires in order
+        if (IMGIN && IDV_IMG_DMA) {
+            // every copy instruction sits in time tap 0, so the 10 * MT_W weight loads of time tap 1 are younger
+            if (AD > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * MT_W) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
+    };
+    {
+        int chunk = 0;
+        for (; chunk + UNR <= nchunk; chunk += UNR) {
+            chunk_body(chunk, IntC<0>{});
+            if constexpr (UNR > 1) chunk_body(chunk + 1, IntC<1>{});
+            if constexpr (UNR > 2) chunk_body(chunk + 2, IntC<2>{});
+        }
+        if constexpr (UNR > 1) {
+            if (chunk < nchunk) chunk_body(chunk, IntC<0>{});
+            if constexpr (UNR > 2) {
+                if (chunk + 1 < nchunk) chunk_body(chunk + 1, IntC<1>{});
+            }
+        }
     }
 
     // ------------------------------------------------------------------ epilogue (as cgemm.hpp, !SWAP)
+    if (a.out_img && bid == 0 && tid < 2) {                  // the destination image's zero slot (hi and lo plane)
+        unsigned short* z = (unsigned short*)a.out_img + IDV_IMG_ZSLOT * 8 + (tid ? a.out_lo_off : 0);
+        *(uint4*)z = make_uint4(0u, 0u, 0u, 0u);
+    }
     const float slope = a.slope ? *a.slope : 1.0f;
     const bool has_act = a.slope != nullptr;
 #pragma unroll
@@ -270,9 +417,29 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
                     float t = v[r] + bia[r];
                     if (has_act) t = t >= 0.f ? t : slope * t;
                     y[r] = keep ? t : 0.f;
-                    if (m < a.M && inb) {
+                    if (a.out && m < a.M && inb) {
                         const int plane = (m & 1) * a.Cout + (m >> 1);
                         a.out[((size_t)plane * a.Fout + fo) * a.Jp + j] = y[r];
+                    }
+                }
+                if (a.out_img && inb) {
+                    // split image [hi|lo][octet = m/8][fo][j][8]: this lane owns elements 4*half .. 4*half+3 of 4 octets
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (mt * 32 + 8 * g >= a.M) continue;
+                        unsigned hw[2], lw[2];
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            const float x0 = y[4 * g + 2 * w], x1 = y[4 * g + 2 * w + 1];
+                            const unsigned u0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u;
+                            const unsigned u1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
+                            hw[w] = (u0 >> 16) | u1;
+                            lw[w] = pack_bf16(x0 - __builtin_bit_cast(float, u0), x1 - __builtin_bit_cast(float, u1));
+                        }
+                        unsigned short* d = (unsigned short*)a.out_img +
+                                            (((size_t)(mt * 4 + g) * a.Fout + fo) * a.Jp + j) * 8 + 4 * half;
+                        *(uint2*)d = make_uint2(hw[0], hw[1]);
+                        *(uint2*)(d + a.out_lo_off) = make_uint2(lw[0], lw[1]);
                     }
                 }
                 if (STATS) {
@@ -302,7 +469,7 @@ __global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) 
     }
 }
 
-template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS, int MT_W = 1>
+template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS, int MT_W = 1, bool IMGIN = false, int AD = 2>
 int launch_bf16(const CgemmArgs& a, hipStream_t st) {
     using G = CgemmGeom<MODE, FO_T>;
     constexpr int JT = 32 * JC_W * WN;
@@ -319,7 +486,7 @@ int launch_bf16(const CgemmArgs& a, hipStream_t st) {
     const long long tiles = (long long)b.jtiles * b.ftiles;
     const long long nblk = ((tiles + 7) / 8) * 8 * b.mblocks;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = cgemm_bf16_kernel<MODE, WM, WN, FO_T, JC_W, STATS, MT_W>;
+    auto k = cgemm_bf16_kernel<MODE, WM, WN, FO_T, JC_W, STATS, MT_W, IMGIN, AD>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return IDV_ELAUNCH;
@@ -439,4 +606,58 @@ extern "C" int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, 
         IDV_BF16_DISPATCH(IDV_CONV)
     }
 #undef IDV_BF16_DISPATCH
+}
+
+// Image-source form: x0 / x1 are split images (hi plane at the pointer, lo plane lo_off 16-byte slots further), the
+// destination is a planar fp32 buffer, a split image, or both.  Eval mode only (no statistics).
+extern "C" int idv_cconv2d_img_fwd(int src_is_image, const void* x0_img, long long lo_off0, int C0, const void* x1_img, long long lo_off1,
+                                   int C1, const void* wfrag_bf16, const float* bias, const float* prelu_slope,
+                                   float* out_planar, void* out_img, long long out_lo_off,
+                                   int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out,
+                                   void* stream) {
+    if (!x0_img || !wfrag_bf16 || !bias || (!out_planar && !out_img) || C0 <= 0 || Cout <= 0 || Fin <= 0 ||
+        B <= 0 || Tp <= 1)
+        return IDV_EINVAL;
+    if (!idv_cconv_bf16_supported(transposed, C0, C1, 1, Cout) || (Cout % 4)) return IDV_EINVAL;
+    if (C1 > 0 && (!x1_img || (reinterpret_cast<uintptr_t>(x1_img) & 15))) return IDV_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x0_img) & 15) || (tshift != 0 && tshift != -1))
+        return IDV_EINVAL;
+    if (out_img && ((reinterpret_cast<uintptr_t>(out_img) & 15) || (out_lo_off % 8))) return IDV_EINVAL;
+    CgemmArgs a{};
+    a.x0 = (const float*)x0_img; a.x1 = (const float*)x1_img; a.C0 = C0; a.C1 = C1;
+    a.lo_off0 = lo_off0; a.lo_off1 = lo_off1;
+    a.Fin = Fin;
+    a.Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.Jp1 = Jp; a.x1_div = 1;
+    a.wfrag = (const float*)wfrag_bf16; a.bias = bias; a.slope = prelu_slope; a.out = out_planar;
+    a.out_img = out_img; a.out_lo_off = out_lo_off;
+    a.M = 2 * Cout; a.Mtiles = (a.M + 31) / 32; a.cplx_rows = 1; a.Cout = Cout;
+    a.tshift = tshift; a.t_valid = t_valid_out; a.stats = nullptr; a.ldo = 0; a.nB = B;
+    if (Jp < a.J || (long long)((2 * (C0 > C1 ? C0 : C1) + 7) / 8) * Fin * Jp > 0x7fffff00LL) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = transposed ? Fin : a.Fout;
+    const bool fo5 = waste(rows, 5) <= waste(rows, 3);
+    const bool wide = a.M >= 128;
+    if (!src_is_image) {                                     // planar fp32 sources (as idv_cconv2d_bf16x3_fwd), image output
+        if ((Jp % 4)) return IDV_EINVAL;
+        if (!transposed) {
+            if (a.M >= 256)
+                return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, false, 2>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 2, false, 2>(a, st);
+            if (wide)
+                return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, false>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 1, false>(a, st);
+            return fo5 ? launch_bf16<IDV_CONV, 2, 2, 5, 1, false>(a, st) : launch_bf16<IDV_CONV, 2, 2, 3, 1, false>(a, st);
+        }
+        if (wide) return fo5 ? launch_bf16<IDV_TCONV, 4, 1, 5, 1, false>(a, st) : launch_bf16<IDV_TCONV, 4, 1, 3, 2, false>(a, st);
+        return fo5 ? launch_bf16<IDV_TCONV, 2, 2, 5, 1, false>(a, st) : launch_bf16<IDV_TCONV, 2, 2, 3, 1, false>(a, st);
+    }
+    if (!transposed) {
+        if (a.M >= 256)
+            return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, false, 2, true>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 2, false, 2, true>(a, st);
+        if (wide)
+            return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, false, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 1, false, 1, true, IDV_AD>(a, st);
+        return fo5 ? launch_bf16<IDV_CONV, 2, 2, 5, 1, false, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_CONV, 2, 2, 3, 1, false, 1, true, IDV_AD>(a, st);
+    }
+    if (wide)
+        return fo5 ? launch_bf16<IDV_TCONV, 4, 1, 5, 1, false, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_TCONV, 4, 1, 3, 2, false, 1, true, IDV_AD>(a, st);
+    return fo5 ? launch_bf16<IDV_TCONV, 2, 2, 5, 1, false, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_TCONV, 2, 2, 3, 1, false, 1, true, IDV_AD>(a, st);
 }

@@ -110,8 +110,10 @@ class _ComplexConvBase(nn.Module):
         return self._cache_bf16.get((re.weight, im.weight, fold), cin_used, lambda: ops.pack_cconv_bf16(
             re.weight.detach(), im.weight.detach(), fold, cin_used, self._transposed))
 
-    def forward_planar(self, x: Planar, *, skip: Optional[Planar] = None, skip_div: int = 1, fold=None, slope=None,
-                       stats=None, zero_skip: bool = False) -> Planar:
+    def forward_planar(self, x, *, skip=None, skip_div: int = 1, fold=None, slope=None,
+                       stats=None, zero_skip: bool = False, want: str = "planar"):
+        """x / skip: Planar or ops.Image.  want: "planar" -> Planar, "image" -> ops.Image, "both" -> (Planar, Image).
+        Images are the eval-mode bf16x3 inter-layer format; any other combination converts at the edges."""
         self._check_supported()
         cin_used = x.C if zero_skip else None
         if not zero_skip and x.C + (skip.C if skip is not None else 0) != self.in_channel:
@@ -119,6 +121,23 @@ class _ComplexConvBase(nn.Module):
         wfrag, bias = self.packed(fold, cin_used)
         wbf = None
         c1 = skip.C if skip is not None else 0
+        any_img = isinstance(x, ops.Image) or isinstance(skip, ops.Image)
+        if any_img or want != "planar":
+            img_ok = (ops.PRECISION == "bf16x3" and stats is None and skip_div == 1 and self.out_channel % 4 == 0
+                      and ops.bf16_supported(self._transposed, x.C, c1, 1, self.out_channel))
+            if img_ok:
+                if any_img:                                  # one source format per launch: lift the planar one
+                    x = x if isinstance(x, ops.Image) else ops.to_image(x)
+                    skip = skip if (skip is None or isinstance(skip, ops.Image)) else ops.to_image(skip)
+                outp, outi = ops.cconv2d_img(x, self.packed_bf16(fold, cin_used), bias, self.out_channel,
+                                             transposed=self._transposed, causal=self._causal, slope=slope, skip=skip,
+                                             want_planar=want != "image", want_image=want != "planar")
+                return outp if want == "planar" else (outi if want == "image" else (outp, outi))
+            x = ops.to_planar(x) if isinstance(x, ops.Image) else x
+            skip = ops.to_planar(skip) if isinstance(skip, ops.Image) else skip
+            outp = self.forward_planar(x, skip=skip, skip_div=skip_div, fold=fold, slope=slope, stats=stats,
+                                       zero_skip=zero_skip)
+            return outp if want == "planar" else (ops.to_image(outp) if want == "image" else (outp, ops.to_image(outp)))
         if (ops.PRECISION == "bf16x3" and self._transposed and self._causal and self.out_channel == 1 and stats is None
                 and skip_div == 1 and x.C % 8 == 0 and c1 % 8 == 0):
             re, im = self._re, self._im

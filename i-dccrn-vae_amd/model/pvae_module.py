@@ -83,6 +83,8 @@ class _Block(nn.Module):
     def _run(self, conv, x: Planar, train: bool, **kw) -> Planar:
         slope = self.prelu.weight.detach()
         if train:
+            if kw.get("want", "planar") != "planar":
+                raise RuntimeError("split images are an eval-mode format (train-mode CBN normalises planar fp32 in place)")
             stats = torch.zeros(conv.out_channel, 5, dtype=torch.float64, device=x.buf.device)
             y = conv.forward_planar(x, stats=stats, **kw)
             return self.bn.finish_train(y, stats, slope)
@@ -102,8 +104,8 @@ class Encoder(_Block):
         self.bn = ComplexBatchNormal(chw[0], chw[1], chw[2])
         self.prelu = nn.PReLU()
 
-    def forward_planar(self, x: Planar, train: bool) -> Planar:
-        return self._run(self.conv, x, train)
+    def forward_planar(self, x, train: bool, want: str = "planar"):
+        return self._run(self.conv, x, train, want=want)
 
     def forward(self, x, train):
         return tag5(self.forward_planar(planar_of(x), train))
@@ -121,9 +123,9 @@ class Decoder(_Block):
         self.prelu = nn.PReLU()
         self.if_bn = if_bn
 
-    def forward_planar(self, x: Planar, train: bool = True, skip: Optional[Planar] = None, skip_div: int = 1,
-                       zero_skip: bool = False) -> Planar:
-        kw = dict(skip=skip, skip_div=skip_div, zero_skip=zero_skip)
+    def forward_planar(self, x, train: bool = True, skip=None, skip_div: int = 1,
+                       zero_skip: bool = False, want: str = "planar"):
+        kw = dict(skip=skip, skip_div=skip_div, zero_skip=zero_skip, want=want)
         if not self.if_bn:
             return self.transconv.forward_planar(x, **kw)
         return self._run(self.transconv, x, train, **kw)
@@ -186,6 +188,8 @@ class standard_DCCRN(nn.Module):
         self.detect_anormal = True
 
     def forward_planar(self, x: Planar, train: bool = True, on_encoded=None) -> Planar:
+        if not train and ops.PRECISION == "bf16x3" and ops.IMAGE_PATH:
+            return self._forward_images(x, on_encoded)
         skips = _run_encoders(self.encoders, x, train)
         if on_encoded is not None:
             on_encoded()
@@ -198,6 +202,47 @@ class standard_DCCRN(nn.Module):
         p = self.dense.forward_planar(lat, top.C, top.F)
         for i, dec in enumerate(self.decoders):
             p = dec.forward_planar(p, train, skip=skips[len(skips) - 1 - i] if i in self.skip_to_use else None)
+        return p
+
+    def _forward_images(self, x: Planar, on_encoded=None) -> Planar:
+        """Eval bf16x3: activations between conv blocks live as split-bf16 images (ops.Image) that the next kernel
+        copies into LDS verbatim; planar fp32 only where a non-conv consumer needs it (LSTM input, the Cout = 1
+        last block and its skip, the mask).  Same arithmetic as the planar bf16x3 path, bit for bit."""
+        n = len(self.encoders)
+        skips = []                                                  # per encoder: what the decoder side will read
+        top = None
+        for i, enc in enumerate(self.encoders):
+            last = i == n - 1
+            nxt_needs_planar = last                                 # LSTM projection reads planar fp32
+            dec_i = n - 1 - i                                       # decoder that takes this output as its skip
+            skip_planar = dec_i in self.skip_to_use and self.decoders[dec_i].transconv.out_channel % 4 != 0
+            if i == 0 and enc.conv.in_channel % 4 != 0:
+                want = "planar"                                     # fp32 kernel (Cin = 1); the next block lifts it if needed
+            elif nxt_needs_planar or skip_planar:
+                want = "both"
+            else:
+                want = "image"
+            y = enc.forward_planar(x, False, want=want)
+            if want == "both":
+                top, x = y
+                skips.append(y[0] if skip_planar else y[1])
+            else:
+                top = x = y
+                skips.append(y)
+        if on_encoded is not None:
+            on_encoded()
+        if not isinstance(top, Planar):
+            top = ops.to_planar(top)
+        lat = top
+        for lstm in self.lstms:
+            lat = lstm.forward_planar(lat)
+        self.latent = _lstm_out_view(lat, 0, lat.C)                # [B, T, H, 2]
+        p = self.dense.forward_planar(lat, top.C, top.F)
+        nd = len(self.decoders)
+        for i, dec in enumerate(self.decoders):
+            nxt = self.decoders[i + 1].transconv if i + 1 < nd else None
+            want = "image" if (nxt is not None and nxt.out_channel % 4 == 0) else "planar"
+            p = dec.forward_planar(p, False, skip=skips[n - 1 - i] if i in self.skip_to_use else None, want=want)
         return p
 
     def forward(self, x, train=True):

@@ -95,6 +95,47 @@ class Planar:
         return out
 
 
+IMG_SLACK = 4096          # bf16 elements kept readable before, between and after the two planes of an Image
+IMAGE_PATH = os.environ.get("IDV_IMAGE_PATH", "1") != "0"     # eval bf16x3: keep inter-layer activations as split images
+
+
+class Image:
+    """A split-bf16 activation image  img[hi|lo][(2C+7)//8][F][Jp][8]  (include/idccrn_hip.h, "split image"): what the
+    bf16x3 conv kernels stage into LDS verbatim.  Same (C, F, B, T, Tp, Jp) meaning as Planar."""
+
+    __slots__ = ("buf", "C", "F", "B", "T", "Tp", "Jp", "lo_off")
+
+    def __init__(self, buf, C, F, B, T, Tp, Jp, lo_off):
+        self.buf, self.C, self.F, self.B, self.T, self.Tp, self.Jp, self.lo_off = buf, C, F, B, T, Tp, Jp, lo_off
+
+    @classmethod
+    def empty(cls, C, F, B, T, Tp, device):
+        Jp = Planar.jp_for(B, Tp)
+        plane = (2 * C + 7) // 8 * F * Jp * 8
+        lo_off = plane + IMG_SLACK
+        buf = torch.empty(bucket(2 * IMG_SLACK + lo_off + plane), dtype=torch.int16, device=device)
+        return cls(buf, C, F, B, T, Tp, Jp, lo_off)
+
+    def ptr(self):
+        return L._P(self.buf.data_ptr() + 2 * IMG_SLACK)
+
+    @property
+    def lo_slots(self) -> int:
+        return self.lo_off // 8
+
+
+def to_image(x: Planar) -> Image:
+    out = Image.empty(x.C, x.F, x.B, x.T, x.Tp, x.buf.device)
+    call("idv_planar_to_image", x.ptr(), i(x.C), i(x.F), i(x.B * x.Tp), i(x.Jp), out.ptr(), ll(out.lo_off), stream_ptr())
+    return out
+
+
+def to_planar(x: Image) -> Planar:
+    out = Planar.empty(x.C, x.F, x.B, x.T, x.Tp, x.buf.device)
+    call("idv_image_to_planar", x.ptr(), ll(x.lo_off), i(x.C), i(x.F), i(x.B * x.Tp), i(x.Jp), out.ptr(), stream_ptr())
+    return out
+
+
 def _dev_scratch(n: int, device, dtype=torch.float32, zero=False):
     return (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=device)
 
@@ -253,6 +294,37 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
         ev1.record()
         LAUNCH_LOG.append((cfg, macs, ev0, ev1))
     return out
+
+
+def cconv2d_img(x, wfrag_bf16, bias, cout: int, *, transposed=False, causal=True, slope=None, skip=None,
+                want_planar=False, want_image=True):
+    """Eval-mode conv / transposed conv on the split-bf16 path with image and/or planar sources (x and skip must share
+    one format) -> (Planar or None, Image or None)."""
+    src_img = isinstance(x, Image)
+    if skip is not None and isinstance(skip, Image) != src_img:
+        raise RuntimeError("cconv2d_img: x and skip must have the same format")
+    Fout = 2 * x.F - 1 if transposed else (x.F - 1) // 2 + 1
+    t_out = x.T if causal else (x.T + 1 if transposed else x.T - 1)
+    tshift = -1 if (causal or transposed) else 0
+    dev = x.buf.device
+    outp = Planar.empty(cout, Fout, x.B, t_out, x.Tp, dev) if want_planar else None
+    outi = Image.empty(cout, Fout, x.B, t_out, x.Tp, dev) if want_image else None
+    c1 = skip.C if skip is not None else 0
+    if LAUNCH_LOG is not None:
+        cfg = -((2000000 if src_img else 1000000) + L.lib().idv_cconv_bf16_config(i(1 if transposed else 0), i(cout), i(x.F)))
+        pos = x.B * x.T * (x.F if transposed else Fout)
+        macs = 4 * (x.C + c1) * cout * 10 * pos
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    call("idv_cconv2d_img_fwd", i(1 if src_img else 0), x.ptr(), ll(x.lo_slots if src_img else 0), i(x.C),
+         skip.ptr() if skip is not None else p(None), ll(skip.lo_slots if (skip is not None and src_img) else 0), i(c1),
+         p(wfrag_bf16), p(bias), p(slope), outp.ptr() if outp is not None else p(None),
+         outi.ptr() if outi is not None else p(None), ll(outi.lo_off if outi is not None else 0),
+         i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+    if LAUNCH_LOG is not None:
+        ev1.record()
+        LAUNCH_LOG.append((cfg, macs, ev0, ev1))
+    return outp, outi
 
 
 def pw_gemm(x_ptr, K: int, wfrag, bias, M: int, B: int, Tp: int, Jp: int, t_valid: int, out_ptr, *, slope=None,

@@ -96,6 +96,23 @@ int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, int C1, int
                            const float* bias, const float* prelu_slope, float* out, double* stats, int transposed,
                            int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
 
+/* Split image: the inter-layer activation format of the bf16x3 path (eval mode).  bf16 elements,
+ *   image[hi|lo][octet o][F][Jp][8],  element e of octet o = planar channel cc = 8*o + e = 2*ci + ri,
+ * hi = value truncated to bf16, lo = round-to-nearest bf16 of the remainder (hi + lo reproduces the fp32 value to
+ * ~2^-17, exactly the operand split idv_cconv2d_bf16x3_fwd applies while staging, so both entries give identical
+ * results).  The lo plane starts lo_off elements (idv_cconv2d_img_fwd sources: 16-byte slots) after the hi plane;
+ * callers keep >= 256 readable and writable bytes before each plane (every producer zeroes the 16-byte slot
+ * 128 bytes before each plane; consumers read it for out-of-range frequency rows) and 4 KiB after them.
+ * idv_cconv2d_img_fwd: same contraction, folded BN and PReLU epilogue as idv_cconv2d_bf16x3_fwd (reference
+ * model/complex_progress.py:16-22, :244-250; pvae_module.py:64-68, :88-93) with image sources, writing planar fp32
+ * (out_planar), an image (out_img) or both. */
+int idv_planar_to_image(const float* x, int C, int F, int J, int Jp, void* img, long long lo_off_elems, void* stream);
+int idv_image_to_planar(const void* img, long long lo_off_elems, int C, int F, int J, int Jp, float* x, void* stream);
+int idv_cconv2d_img_fwd(int src_is_image /* 0: x0/x1 are planar fp32 (row stride Jp) */, const void* x0_img, long long lo_off0_slots, int C0, const void* x1_img, long long lo_off1_slots,
+                        int C1, const void* wfrag_bf16, const float* bias, const float* prelu_slope, float* out_planar,
+                        void* out_img, long long out_lo_off_elems, int transposed, int tshift,
+                        int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
+
 /* Last decoder block (Cout = 1): transposed conv re-associated so that the five frequency taps sit in the MFMA
  * M dimension (10 rows instead of 2), taps combined in the epilogue; split-bf16 arithmetic, eval mode only
  * (folded BN + PReLU; train-mode statistics use idv_cconv2d_fwd).  Same reference lines as idv_cconv2d_fwd.

@@ -374,6 +374,53 @@ def test_cconv_bf16x3(ops, causal, transposed, cin, cout, F, T, B, skip_c):
     assert float(y.planes()[..., 0].abs().max()) == 0.0
     if y.planes().shape[-1] > y.T + 1:
         assert float(y.planes()[..., y.T + 1:].abs().max()) == 0.0
+    # split-image form of the same launch: image sources give the identical planar result (same operand split),
+    # the image output decodes to it within the split's 2^-16, and planar sources can write an image too
+    if cout % 4 == 0:
+        xi, ski = ops.to_image(xp), (ops.to_image(skp) if skp is not None else None)
+        back = ops.to_planar(xi)
+        assert float((back.tensor5() - xp.tensor5()).abs().max()) <= 2.0 ** -16 * float(xp.tensor5().abs().max())
+        kw = dict(transposed=transposed, causal=causal, slope=slope)
+        yp, yi = ops.cconv2d_img(xi, wbf, bias, cout, skip=ski, want_planar=True, want_image=True, **kw)
+        assert torch.equal(yp.tensor5(), y.tensor5())
+        dec = ops.to_planar(yi)
+        assert float((dec.tensor5() - y.tensor5()).abs().max()) <= 2.0 ** -16 * float(y.tensor5().abs().max())
+        assert float(dec.planes()[..., 0].abs().max()) == 0.0
+        _, yi2 = ops.cconv2d_img(xp, wbf, bias, cout, skip=skp, want_planar=False, want_image=True, **kw)
+        assert torch.equal(ops.to_planar(yi2).tensor5(), dec.tensor5())
+        yp3, none = ops.cconv2d_img(xi, wbf, bias, cout, skip=ski, want_planar=True, want_image=False, **kw)
+        assert none is None and torch.equal(yp3.tensor5(), y.tensor5())
+
+
+def test_image_path_matches_planar_path(ops, amd):
+    """standard_DCCRN eval on split images (default) vs planar fp32 inter-layer activations: identical arithmetic,
+    so identical waveforms; full-width net (every block on the bf16x3 kernels) and a narrow one (fallbacks)."""
+    import importlib
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    keep = (ops.IMAGE_PATH, ops.PRECISION)
+    try:
+        ops.set_precision("bf16x3")
+        for base, L_, B in ((32, 3000, 3), (8, 2345, 2), (4, 1600, 2)):
+            np_ = O.net_params(True, base)
+            m = pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, [0, 1, 2, 3, 4, 5], "mask", False, None, None)
+            m.load_state_dict(O.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 21))
+            m = m.cuda()
+            g = torch.Generator().manual_seed(base)
+            x = (torch.randn(B, L_, generator=g) * 0.1).cuda()
+            ops.IMAGE_PATH = True
+            c1, p1 = m(x, train=False)
+            lat1 = m.std_DCCRN.latent.clone()
+            ops.IMAGE_PATH = False
+            c0, p0 = m(x, train=False)
+            if base == 32:
+                assert torch.equal(c1, c0), (base, float((c1 - c0).abs().max()))
+                assert torch.equal(torch.view_as_real(p1), torch.view_as_real(p0))
+                assert torch.equal(lat1, m.std_DCCRN.latent)
+            else:       # narrow blocks fall back to the fp32 kernel, which then reads an image decoded to hi + lo (2^-17)
+                assert relerr(c1, c0) < 1e-5 and relerr(lat1, m.std_DCCRN.latent) < 1e-5
+    finally:
+        ops.IMAGE_PATH = keep[0]
+        ops.set_precision(keep[1])
 
 
 def test_bf16x3_train_stats_and_model(ops, amd, golden):
