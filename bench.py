@@ -252,8 +252,12 @@ def main():
             d = str(cfg_id)
             mode, t = (1 if len(d) == 7 else 0), d[-6:]
             return f"void cgemm_kernel<{mode}, {t[0]}, {t[1]}, {t[2]}, {t[3]}, {t[4]}, {t[5]}, false, false, true>(CgemmArgs)"
+        if cfg_id <= -100000000:       # idv_cconv_img_config digits <MODE, WM, WN, FO_T, JC_W, MT_W, IMGIN, AD>
+            d = str(-cfg_id - 100000000).rjust(8, "0")
+            return (f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false, {d[5]}, "
+                    f"{'true' if d[6] == '1' else 'false'}, {d[7]}>(CgemmArgs)")
         d = str(-cfg_id - 1000000).rjust(6, "0")
-        return f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false, {d[5]}>(CgemmArgs)"
+        return f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false, {d[5]}, false, 2>(CgemmArgs)"
 
     def group(entries):
         out = {}

@@ -96,6 +96,28 @@ extern "C" int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     return stats ? launch_conv<true>(a, mode, st) : launch_conv<false>(a, mode, st);
 }
 
+// idv_cconv2d_fwd (eval mode, x1_div == 1) that can also / instead write its result as a split-bf16 image
+extern "C" int idv_cconv2d_fwd_img(const float* x0, int C0, const float* x1, int C1, int Jp1, const float* wfrag,
+                                   const float* bias, const float* prelu_slope, float* out_planar, void* out_img,
+                                   long long out_lo_off, int transposed, int tshift, int Cout, int Fin, int B, int Tp,
+                                   int Jp, int t_valid_out, void* stream) {
+    if (!x0 || !wfrag || !bias || (!out_planar && !out_img) || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1)
+        return IDV_EINVAL;
+    if ((C1 > 0 && !x1) || (tshift != 0 && tshift != -1)) return IDV_EINVAL;
+    if (out_img && ((Cout % 4) || (out_lo_off % 8) || (reinterpret_cast<uintptr_t>(out_img) & 15))) return IDV_EINVAL;
+    CgemmArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1;
+    a.Fin = Fin;
+    a.Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.Jp1 = Jp1; a.x1_div = 1;
+    a.wfrag = wfrag; a.bias = bias; a.slope = prelu_slope; a.out = out_planar;
+    a.out_img = out_img; a.out_lo_off = out_lo_off;
+    a.M = 2 * Cout; a.Mtiles = (a.M + 31) / 32; a.cplx_rows = 1; a.Cout = Cout;
+    a.tshift = tshift; a.t_valid = t_valid_out; a.stats = nullptr; a.ldo = 0; a.nB = B;
+    if (Jp < a.J) return IDV_EINVAL;
+    return launch_conv<false>(a, transposed ? IDV_TCONV : IDV_CONV, (hipStream_t)stream);
+}
+
 extern "C" int idv_pw_gemm(const float* x, int K, const float* wfrag, const float* bias, const float* prelu_slope,
                            float* out, int M, int B, int Tp, int Jp, int t_valid, int swap, int ldo, void* stream) {
     if (!x || !wfrag || !bias || !out || K <= 0 || (K & 1) || M <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;

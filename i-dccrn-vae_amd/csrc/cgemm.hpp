@@ -56,6 +56,12 @@ struct CgemmArgs {
 // consumers read it for frequency rows outside [0, Fin)
 #define IDV_IMG_ZSLOT (-8)
 
+typedef __bf16 idv_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned idv_pack_bf16(float a, float b) {      // round-to-nearest-even pair
+    idv_bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
 template <int MODE, int FO_T>
 struct CgemmGeom {
     static constexpr int KF = (MODE == IDV_PW) ? 1 : 5;
@@ -329,6 +335,10 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
     }
 
     // ------------------------------------------------------------------ epilogue
+    if (a.out_img && blockIdx.x == 0 && tid < 2) {           // the destination image's zero slot (hi and lo plane)
+        unsigned short* z = (unsigned short*)a.out_img + IDV_IMG_ZSLOT * 8 + (tid ? a.out_lo_off : 0);
+        *(uint4*)z = make_uint4(0u, 0u, 0u, 0u);
+    }
     const float slope = a.slope ? *a.slope : 1.0f;
     const bool has_act = a.slope != nullptr;
     const int half = lane >> 5, l31 = lane & 31;
@@ -370,9 +380,29 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
                         float t = v[r] + bia[r];
                         if (has_act) t = t >= 0.f ? t : slope * t;
                         y[r] = keep ? t : 0.f;
-                        if (m < a.M && inb) {
+                        if (a.out && m < a.M && inb) {
                             const int plane = a.cplx_rows ? ((m & 1) * a.Cout + (m >> 1)) : m;
                             a.out[((size_t)plane * a.Fout + fo) * a.Jp + j] = y[r];
+                        }
+                    }
+                    if (a.out_img && inb) {
+                        // split-bf16 image for the bf16x3 consumers (layout: idccrn_hip.h "split image")
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            if (mt * 32 + 8 * g >= a.M) continue;
+                            unsigned hw[2], lw[2];
+#pragma unroll
+                            for (int w = 0; w < 2; ++w) {
+                                const float x0 = y[4 * g + 2 * w], x1 = y[4 * g + 2 * w + 1];
+                                const unsigned u0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u;
+                                const unsigned u1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
+                                hw[w] = (u0 >> 16) | u1;
+                                lw[w] = idv_pack_bf16(x0 - __builtin_bit_cast(float, u0), x1 - __builtin_bit_cast(float, u1));
+                            }
+                            unsigned short* d = (unsigned short*)a.out_img +
+                                                (((size_t)(mt * 4 + g) * a.Fout + fo) * a.Jp + j) * 8 + 4 * half;
+                            *(uint2*)d = make_uint2(hw[0], hw[1]);
+                            *(uint2*)(d + a.out_lo_off) = make_uint2(lw[0], lw[1]);
                         }
                     }
                     if (STATS) {

@@ -29,7 +29,7 @@ struct IntC { static constexpr int value = K; };
 // AD: depth of the weight-fragment ring in phases (one phase = the 5 frequency taps of one time tap of one chunk);
 // fragments are fetched AD-1 phases ahead of their use.
 template <int MODE, int WM, int WN, int FO_T, int JC_W, bool STATS, int MT_W = 1, bool IMGIN = false, int AD = 2>
-__global__ __launch_bounds__(WM* WN * 64, (FO_T == 3 && JC_W == 1 && MT_W == 1) ? 2 : 1) void cgemm_bf16_kernel(const CgemmArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, ((FO_T == 3 && JC_W == 1 && MT_W == 1) || (IMGIN && AD == 2 && JC_W == 1 && MT_W == 1)) ? 2 : 1) void cgemm_bf16_kernel(const CgemmArgs a) {
     using G = CgemmGeom<MODE, FO_T>;
     constexpr int NT = WM * WN * 64;
     constexpr int KF = 5, FR = G::FR, ROWS = G::ROWS;
@@ -608,6 +608,36 @@ extern "C" int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, 
 #undef IDV_BF16_DISPATCH
 }
 
+// <MODE, WM, WN, FO_T, JC_W, MT_W, IMGIN, AD> (as decimal digits) of the instantiation idv_cconv2d_img_fwd launches:
+// the one place the tiling policy lives (measured at B = 64 on the DCCRN-CL layer shapes)
+static int img_cfg(int src_is_image, int transposed, int M, int cin, int Fin) {
+    const int rows = transposed ? Fin : (Fin - 1) / 2 + 1;
+    const bool fo5 = waste(rows, 5) <= waste(rows, 3);
+    const bool wide = M >= 128;
+    const int img = src_is_image ? 1 : 0;
+    int wm = 4, wn = 1, fo = fo5 ? 5 : 3, jc = 1, mt = 1, ad = img ? IDV_AD : 2;
+    if (!transposed) {
+        if (M >= 256) {                       // two row tiles per wave halve the staging and the B reads per MFMA
+            jc = fo5 ? 1 : 2; mt = 2; ad = 2;
+        } else if (wide) {
+            // short K (few chunks): two workgroups per CU (a 2-deep weight ring keeps each under 256 registers)
+            // overlap one workgroup's prologue / epilogue with the other's MFMAs
+            if (img && fo5 && cin <= 64) ad = 2;
+        } else {
+            wm = 2; wn = 2;
+        }
+    } else if (wide) {
+        jc = fo5 ? 1 : 2;
+    } else {
+        wm = 2; wn = 2;
+    }
+    return ((((((transposed ? 1 : 0) * 10 + wm) * 10 + wn) * 10 + fo) * 10 + jc) * 10 + mt) * 100 + img * 10 + ad;
+}
+
+extern "C" int idv_cconv_img_config(int src_is_image, int transposed, int Cin, int Cout, int Fin) {
+    return img_cfg(src_is_image, transposed, 2 * Cout, Cin, Fin);
+}
+
 // Image-source form: x0 / x1 are split images (hi plane at the pointer, lo plane lo_off 16-byte slots further), the
 // destination is a planar fp32 buffer, a split image, or both.  Eval mode only (no statistics).
 extern "C" int idv_cconv2d_img_fwd(int src_is_image, const void* x0_img, long long lo_off0, int C0, const void* x1_img, long long lo_off1,
@@ -635,29 +665,21 @@ extern "C" int idv_cconv2d_img_fwd(int src_is_image, const void* x0_img, long lo
     a.tshift = tshift; a.t_valid = t_valid_out; a.stats = nullptr; a.ldo = 0; a.nB = B;
     if (Jp < a.J || (long long)((2 * (C0 > C1 ? C0 : C1) + 7) / 8) * Fin * Jp > 0x7fffff00LL) return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int rows = transposed ? Fin : a.Fout;
-    const bool fo5 = waste(rows, 5) <= waste(rows, 3);
-    const bool wide = a.M >= 128;
-    if (!src_is_image) {                                     // planar fp32 sources (as idv_cconv2d_bf16x3_fwd), image output
-        if ((Jp % 4)) return IDV_EINVAL;
-        if (!transposed) {
-            if (a.M >= 256)
-                return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, false, 2>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 2, false, 2>(a, st);
-            if (wide)
-                return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, false>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 1, false>(a, st);
-            return fo5 ? launch_bf16<IDV_CONV, 2, 2, 5, 1, false>(a, st) : launch_bf16<IDV_CONV, 2, 2, 3, 1, false>(a, st);
-        }
-        if (wide) return fo5 ? launch_bf16<IDV_TCONV, 4, 1, 5, 1, false>(a, st) : launch_bf16<IDV_TCONV, 4, 1, 3, 2, false>(a, st);
-        return fo5 ? launch_bf16<IDV_TCONV, 2, 2, 5, 1, false>(a, st) : launch_bf16<IDV_TCONV, 2, 2, 3, 1, false>(a, st);
+    if (!src_is_image && (Jp % 4)) return IDV_EINVAL;
+    switch (img_cfg(src_is_image, transposed, a.M, C0 + C1, Fin)) {
+#define IDV_CASE(MODE, WM, WN, FO, JC, MT, IMG, AD)                                                   \
+    case ((((((MODE * 10 + WM) * 10 + WN) * 10 + FO) * 10 + JC) * 10 + MT) * 10 + IMG) * 10 + AD:    \
+        return launch_bf16<MODE, WM, WN, FO, JC, false, MT, (IMG != 0), AD>(a, st);
+        IDV_CASE(0, 4, 1, 5, 1, 2, 0, 2) IDV_CASE(0, 4, 1, 3, 2, 2, 0, 2) IDV_CASE(0, 4, 1, 5, 1, 1, 0, 2)
+        IDV_CASE(0, 4, 1, 3, 1, 1, 0, 2) IDV_CASE(0, 2, 2, 5, 1, 1, 0, 2) IDV_CASE(0, 2, 2, 3, 1, 1, 0, 2)
+        IDV_CASE(1, 4, 1, 5, 1, 1, 0, 2) IDV_CASE(1, 4, 1, 3, 2, 1, 0, 2) IDV_CASE(1, 2, 2, 5, 1, 1, 0, 2)
+        IDV_CASE(1, 2, 2, 3, 1, 1, 0, 2)
+        IDV_CASE(0, 4, 1, 5, 1, 2, 1, 2) IDV_CASE(0, 4, 1, 3, 2, 2, 1, 2) IDV_CASE(0, 4, 1, 5, 1, 1, 1, 2)
+        IDV_CASE(0, 4, 1, 5, 1, 1, 1, IDV_AD) IDV_CASE(0, 4, 1, 3, 1, 1, 1, IDV_AD) IDV_CASE(0, 2, 2, 5, 1, 1, 1, IDV_AD)
+        IDV_CASE(0, 2, 2, 3, 1, 1, 1, IDV_AD)
+        IDV_CASE(1, 4, 1, 5, 1, 1, 1, IDV_AD) IDV_CASE(1, 4, 1, 3, 2, 1, 1, IDV_AD) IDV_CASE(1, 2, 2, 5, 1, 1, 1, IDV_AD)
+        IDV_CASE(1, 2, 2, 3, 1, 1, 1, IDV_AD)
+#undef IDV_CASE
     }
-    if (!transposed) {
-        if (a.M >= 256)
-            return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, false, 2, true>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 2, false, 2, true>(a, st);
-        if (wide)
-            return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, false, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 1, false, 1, true, IDV_AD>(a, st);
-        return fo5 ? launch_bf16<IDV_CONV, 2, 2, 5, 1, false, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_CONV, 2, 2, 3, 1, false, 1, true, IDV_AD>(a, st);
-    }
-    if (wide)
-        return fo5 ? launch_bf16<IDV_TCONV, 4, 1, 5, 1, false, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_TCONV, 4, 1, 3, 2, false, 1, true, IDV_AD>(a, st);
-    return fo5 ? launch_bf16<IDV_TCONV, 2, 2, 5, 1, false, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_TCONV, 2, 2, 3, 1, false, 1, true, IDV_AD>(a, st);
+    return IDV_EINVAL;
 }

@@ -135,6 +135,12 @@ class _ComplexConvBase(nn.Module):
                 return outp if want == "planar" else (outi if want == "image" else (outp, outi))
             x = ops.to_planar(x) if isinstance(x, ops.Image) else x
             skip = ops.to_planar(skip) if isinstance(skip, ops.Image) else skip
+            if want != "planar" and stats is None and skip_div == 1 and self.out_channel % 4 == 0 and not (
+                    ops.PRECISION == "bf16x3" and ops.bf16_supported(self._transposed, x.C, c1, 1, self.out_channel)):
+                # exact-fp32 kernel (e.g. the first encoder block, Cin = 1) with an image-writing epilogue
+                outp, outi = ops.cconv2d(x, wfrag, bias, self.out_channel, transposed=self._transposed, causal=self._causal,
+                                         slope=slope, skip=skip, image="only" if want == "image" else "also")
+                return outi if want == "image" else (outp, outi)
             outp = self.forward_planar(x, skip=skip, skip_div=skip_div, fold=fold, slope=slope, stats=stats,
                                        zero_skip=zero_skip)
             return outp if want == "planar" else (ops.to_image(outp) if want == "image" else (outp, ops.to_image(outp)))

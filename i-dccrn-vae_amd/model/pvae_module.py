@@ -216,9 +216,7 @@ class standard_DCCRN(nn.Module):
             nxt_needs_planar = last                                 # LSTM projection reads planar fp32
             dec_i = n - 1 - i                                       # decoder that takes this output as its skip
             skip_planar = dec_i in self.skip_to_use and self.decoders[dec_i].transconv.out_channel % 4 != 0
-            if i == 0 and enc.conv.in_channel % 4 != 0:
-                want = "planar"                                     # fp32 kernel (Cin = 1); the next block lifts it if needed
-            elif nxt_needs_planar or skip_planar:
+            if nxt_needs_planar or skip_planar:
                 want = "both"
             else:
                 want = "image"

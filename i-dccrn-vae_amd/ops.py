@@ -258,17 +258,26 @@ def side_streams(n: int, device):
 
 def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True, slope=None, skip: Optional[Planar] = None,
             skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None,
-            wfrag_bf16: Optional[torch.Tensor] = None) -> Planar:
-    """(causal_)ComplexConv2d / (causal_)ComplexConvTranspose2d forward on planar activations."""
+            wfrag_bf16: Optional[torch.Tensor] = None, image: str = ""):
+    """(causal_)ComplexConv2d / (causal_)ComplexConvTranspose2d forward on planar activations.
+    image="also" / "only": the exact-fp32 kernel additionally / only writes a split-bf16 image -> (Planar|None, Image)."""
     Fout = 2 * x.F - 1 if transposed else (x.F - 1) // 2 + 1
     if causal:
         t_out = x.T
     else:
         t_out = x.T + 1 if transposed else x.T - 1
     tshift = -1 if (causal or transposed) else 0
-    if out is None:
+    if out is None and image != "only":
         out = Planar.empty(cout, Fout, x.B, t_out, x.Tp, x.buf.device)
     c1 = skip.C if skip is not None else 0
+    if image:
+        assert stats is None and skip_div == 1 and wfrag_bf16 is None
+        img = Image.empty(cout, Fout, x.B, t_out, x.Tp, x.buf.device)
+        call("idv_cconv2d_fwd_img", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
+             i(skip.Jp if skip is not None else 0), p(wfrag), p(bias), p(slope), out.ptr() if out is not None else p(None),
+             img.ptr(), ll(img.lo_off), i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp),
+             i(t_out), stream_ptr())
+        return out, img
     if LAUNCH_LOG is not None:
         cfg = L.lib().idv_cconv_config(i(1 if transposed else 0), i(x.C + c1), i(cout), i(x.F))
         # algorithmic MACs: 4 real convolutions of the reference, kernel 5x2, per kept output position
@@ -311,7 +320,8 @@ def cconv2d_img(x, wfrag_bf16, bias, cout: int, *, transposed=False, causal=True
     outi = Image.empty(cout, Fout, x.B, t_out, x.Tp, dev) if want_image else None
     c1 = skip.C if skip is not None else 0
     if LAUNCH_LOG is not None:
-        cfg = -((2000000 if src_img else 1000000) + L.lib().idv_cconv_bf16_config(i(1 if transposed else 0), i(cout), i(x.F)))
+        cfg = -(100000000 + L.lib().idv_cconv_img_config(i(1 if src_img else 0), i(1 if transposed else 0), i(x.C + c1),
+                                                          i(cout), i(x.F)))
         pos = x.B * x.T * (x.F if transposed else Fout)
         macs = 4 * (x.C + c1) * cout * 10 * pos
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

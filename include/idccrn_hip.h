@@ -106,6 +106,12 @@ int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, int C1, int
  * idv_cconv2d_img_fwd: same contraction, folded BN and PReLU epilogue as idv_cconv2d_bf16x3_fwd (reference
  * model/complex_progress.py:16-22, :244-250; pvae_module.py:64-68, :88-93) with image sources, writing planar fp32
  * (out_planar), an image (out_img) or both. */
+int idv_cconv2d_fwd_img(const float* x0, int C0, const float* x1, int C1, int Jp1, const float* wfrag, const float* bias,
+                        const float* prelu_slope, float* out_planar, void* out_img, long long out_lo_off_elems,
+                        int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out,
+                        void* stream);   /* exact-fp32 idv_cconv2d_fwd (eval, x1_div 1) writing planar and/or image */
+int idv_cconv_img_config(int src_is_image, int transposed, int Cin, int Cout, int Fin);   /* template digits <MODE, WM, WN,
+                        FO_T, JC_W, MT_W, IMGIN, AD> of the cgemm_bf16_kernel idv_cconv2d_img_fwd launches (profiles) */
 int idv_planar_to_image(const float* x, int C, int F, int J, int Jp, void* img, long long lo_off_elems, void* stream);
 int idv_image_to_planar(const void* img, long long lo_off_elems, int C, int F, int J, int Jp, float* x, void* stream);
 int idv_cconv2d_img_fwd(int src_is_image /* 0: x0/x1 are planar fp32 (row stride Jp) */, const void* x0_img, long long lo_off0_slots, int C0, const void* x1_img, long long lo_off1_slots,
