@@ -580,7 +580,8 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     float* cstate = h1 + 4 * TB * H;       // [4][B][H], used by the per-step kernel only
     int rc;
     // layer 0 input projection: both weight sets at once (M = 8H), one call per input part z
-    for (int z = 0; z < 2; ++z) {
+    // (flags bit 1: the caller already filled G through idv_lstm_proj_bf16x3)
+    for (int z = 0; z < 2 && !(flags & 2); ++z) {
         rc = idv_pw_gemm(x + (size_t)z * K * Jp, K, wih0, bih0, nullptr, G + (size_t)z * TB * 8 * H, 8 * H, B, Tp, Jp, T, 1,
                          8 * H, stream);
         if (rc) return rc;

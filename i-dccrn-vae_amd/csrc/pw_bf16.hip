@@ -1,0 +1,287 @@
+// Split-precision (bf16x3) form of the point-wise contraction with the transposed ("swap") store: the hoisted LSTM
+// input projection  G[part][(t, b)][m] = sum_k W[m][k] * x[part][k][j] + bias[m]   (reference: nn.LSTM inside
+// ComplexLSTM.forward, model/complex_progress.py:50-74 -- lstm_re / lstm_im applied to the real and the imaginary
+// input; the two weight sets are stacked along m, the two inputs are the two `parts`, so one weight fragment
+// serves both).  Same arithmetic as cgemm_bf16.hip: x = hi + lo, w = hi + lo, three bf16 MFMAs per product, fp32
+// accumulate.
+//
+// The activation comes as a K-major split image  ximg[hi|lo][k octet][Jp][8]  (idv_planar_to_kimage: octet o =
+// planes 8o .. 8o+7 of the planar source), so staging is the same verbatim LDS-DMA copy as the conv path.  MFMA
+// roles are swapped (A = activation: 32 columns j, B = weights: 32 features m) so that a lane's accumulator
+// registers run along j and lanes run along m: the store to the row-major G is 128-byte coalesced.
+//
+// Workgroup: 4 waves x (2 feature tiles of 32) = 256 features x JT = 32*JC columns x NP parts; K stage = 64 k.
+#include "bf16_common.hpp"
+#include "../../include/idccrn_hip.h"
+
+namespace {
+
+struct PwBf16Args {
+    const u32x4* ximg;        // hi plane of the K-major image
+    long long lo_off;         // hi -> lo distance, 16-byte slots
+    long long part_stride;    // slots between the parts' first octets (KO * Jp when the parts are contiguous)
+    int KO;                   // k octets per part (K / 8), a multiple of 8
+    int J, Jp, Tp, t_valid, nB;
+    const uint4* wfrag;       // [m tile][k block of 16][hi|lo][lane] x 16 B
+    const float* bias;        // [M]
+    float* out;               // [part][T*B][ldo]
+    long long out_part_stride;
+    int ldo, M;
+    int jtiles, mblocks;
+};
+
+constexpr int PW_SO = 8;      // octets (of 8 k) per stage
+constexpr int PW_MW = 2;      // feature tiles per wave
+constexpr int PW_RING = 4;    // weight ring depth in k blocks (= k blocks per stage)
+
+template <int JC, int NP>
+__global__ __launch_bounds__(256, 1) void pw_bf16_swap_kernel(const PwBf16Args a) {
+    constexpr int JT = 32 * JC;
+    constexpr int NSLOT = NP * PW_SO * JT;           // 16-byte slots per stage image (hi or lo)
+    constexpr int NLD = NSLOT / 256;
+    static_assert(NSLOT % 256 == 0, "whole staging rounds");
+    constexpr int IMG = NSLOT * 8;                   // bf16 elements of one image
+    constexpr int BUF = 2 * IMG;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware order: the feature blocks of one column tile are consecutive on one XCD (they share the patch)
+    const int MB = a.mblocks;
+    const int bid = blockIdx.x;
+    const int grp = bid / (8 * MB), rem = bid - grp * (8 * MB);
+    const int jt = grp * 8 + (rem & 7);
+    const int mblk = rem >> 3;
+    if (jt >= a.jtiles) return;
+    const int j0 = jt * JT;
+    const int mt0 = (mblk * 4 + wave) * PW_MW;
+
+    f32x16 acc[NP][JC][PW_MW];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+            for (int i = 0; i < PW_MW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][jc][i][r] = 0.f;
+
+    // staging slot t = ((part * SO + octet) * JT + column); columns past J read whatever lies there (dropped outputs)
+    long long soff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int t = tid + i * 256;
+        const int col = t % JT, po = t / JT;
+        const int o = po % PW_SO, p = po / PW_SO;
+        soff[i] = (long long)p * a.part_stride + (long long)o * a.Jp + (j0 + col);
+    }
+    typedef __attribute__((address_space(3))) unsigned short lds_u16;
+    auto stage_dma = [&](int stage, unsigned short* dst, int i_lo, int i_hi) {
+        const u32x4* xh = a.ximg + (long long)stage * PW_SO * a.Jp;
+        const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u16*)(dst + (size_t)wave * 64 * 8));
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (i < i_lo || i >= i_hi) continue;
+            const u32x4* gh = xh + soff[i];
+            const u32x4* gl = gh + a.lo_off;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(gh), "s"(l0 + (unsigned)(i * 256 * 16)) : "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(gl), "s"(l0 + (unsigned)(i * 256 * 16 + IMG * 2)) : "memory");
+        }
+    };
+
+    const int NKB = a.KO / 2;                         // k blocks of 16
+    const int nstage = a.KO / PW_SO;
+    const uint4* wstream = a.wfrag + (size_t)mt0 * NKB * 128 + lane;
+    uint4 w_hi[PW_RING][PW_MW], w_lo[PW_RING][PW_MW];
+    auto load_w = [&](int kb, uint4 (&dh)[PW_MW], uint4 (&dl)[PW_MW]) {
+        const int kk = kb < NKB ? kb : NKB - 1;       // past the end: harmless re-read
+#pragma unroll
+        for (int i = 0; i < PW_MW; ++i) {
+            dh[i] = wstream[((size_t)i * NKB + kk) * 128];
+            dl[i] = wstream[((size_t)i * NKB + kk) * 128 + 64];
+        }
+    };
+
+    stage_dma(0, smem16, 0, NLD);
+#pragma unroll
+    for (int d = 0; d < PW_RING - 1; ++d) load_w(d, w_hi[d], w_lo[d]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int stage = 0; stage < nstage; ++stage) {
+        const unsigned short* P = smem16 + (stage & 1) * BUF;
+        unsigned short* Pn = smem16 + ((stage + 1) & 1) * BUF;
+        const int nxt = stage + 1 < nstage ? stage + 1 : stage;
+#pragma unroll
+        for (int q = 0; q < PW_SO / 2; ++q) {         // k block = octets 2q, 2q+1 of the stage
+            // spread the next patch's copy and the weight prefetch over the stage (see cgemm_bf16.hip)
+            stage_dma(nxt, Pn, (q * NLD) / (PW_SO / 2), ((q + 1) * NLD) / (PW_SO / 2));
+            load_w(stage * (PW_SO / 2) + q + PW_RING - 1, w_hi[(q + PW_RING - 1) % PW_RING], w_lo[(q + PW_RING - 1) % PW_RING]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int jc = 0; jc < JC; ++jc) {
+                    const unsigned short* src = P + ((size_t)((p * PW_SO + 2 * q + half) * JT + jc * 32 + l31)) * 8;
+                    const bf16x8 xh = __builtin_bit_cast(bf16x8, *(const uint4*)src);
+                    const bf16x8 xl = __builtin_bit_cast(bf16x8, *(const uint4*)(src + IMG));
+#pragma unroll
+                    for (int i = 0; i < PW_MW; ++i) {
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, w_hi[q % PW_RING][i]);
+                        const bf16x8 wl = __builtin_bit_cast(bf16x8, w_lo[q % PW_RING][i]);
+                        f32x16 c = acc[p][jc][i];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, c, 0, 0, 0);
+                        acc[p][jc][i] = c;
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // every copy instruction is older than the 2 * MW weight loads of the stage's last k block (vmcnt retires
+        // in order), so those may stay in flight across the barrier
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW_MW) : "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: registers run along j, lanes along m -> out[part][(tp-1)*B + b][m]
+#pragma unroll
+    for (int i = 0; i < PW_MW; ++i) {
+        const int m = (mt0 + i) * 32 + l31;
+        if (m >= a.M) continue;
+        const float bm = a.bias[m];
+#pragma unroll
+        for (int jc = 0; jc < JC; ++jc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + jc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (j >= a.J) continue;
+                const int b = j / a.Tp, tp = j - b * a.Tp;
+                if (tp < 1 || tp > a.t_valid) continue;
+                const size_t row = (size_t)(tp - 1) * a.nB + b;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) a.out[(size_t)p * a.out_part_stride + row * a.ldo + m] = acc[p][jc][i][r] + bm;
+            }
+    }
+}
+
+template <int JC, int NP>
+int launch_pw(const PwBf16Args& a0, hipStream_t st) {
+    constexpr int JT = 32 * JC;
+    constexpr size_t smem = (size_t)2 * 2 * NP * PW_SO * JT * 16;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    PwBf16Args a = a0;
+    a.jtiles = (a.J + JT - 1) / JT;
+    a.mblocks = (a.M + 255) / 256;
+    const long long nblk = (long long)((a.jtiles + 7) / 8) * 8 * a.mblocks;
+    auto k = pw_bf16_swap_kernel<JC, NP>;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return IDV_ELAUNCH;
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), smem, st, a);
+    return idv_launch_status();
+}
+
+// one thread: one (octet, j) slot = 8 consecutive planes
+__global__ void planar_to_kimage_kernel(const float* __restrict__ x, int nplanes, int J, int Jp, unsigned short* __restrict__ img,
+                                        long long lo_off) {
+    const long long n = (long long)(nplanes / 8) * Jp;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % Jp);
+        const long long o = idx / Jp;
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float x0 = 0.f, x1 = 0.f;
+            if (j < J) {
+                x0 = x[(size_t)(8 * o + 2 * w) * Jp + j];
+                x1 = x[(size_t)(8 * o + 2 * w + 1) * Jp + j];
+            }
+            const unsigned u0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u;
+            const unsigned u1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
+            hw[w] = (u0 >> 16) | u1;
+            lw[w] = pack_bf16(x0 - __builtin_bit_cast(float, u0), x1 - __builtin_bit_cast(float, u1));
+        }
+        *(uint4*)(img + idx * 8) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        *(uint4*)(img + lo_off + idx * 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+}
+
+// wfrag[m tile][k block][hi|lo][lane]: lane l holds feature m = 32*mt + (l & 31), k = 16*kb + 8*(l >> 5) .. +7
+__global__ void pack_lstm_ih_bf16_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im, int H, int K,
+                                         uint4* __restrict__ out) {
+    const int M = 8 * H, NKB = K / 16;
+    const long long n = (long long)(M / 32) * NKB * 2 * 64;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        long long t = idx >> 6;
+        const int split = (int)(t & 1); t >>= 1;
+        const int kb = (int)(t % NKB);
+        const int mt = (int)(t / NKB);
+        const int m = mt * 32 + (lane & 31);
+        const int set = m / (4 * H), colp = m % (4 * H);
+        // gate column permutation of the recurrence kernels: colp = ((u/16)*4 + g)*16 + u%16 -> torch row g*H + u
+        const int row = ((colp >> 4) & 3) * H + (colp >> 6) * 16 + (colp & 15);
+        const float* w = (set ? w_im : w_re) + (size_t)row * K + 16 * kb + 8 * (lane >> 5);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = split == 0 ? w[j] : w[j] - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, w[j]) & 0xffff0000u);
+        uint4 o;
+        if (split == 0) {
+            unsigned u[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = __builtin_bit_cast(unsigned, v[j]) >> 16;
+            o = make_uint4(u[0] | (u[1] << 16), u[2] | (u[3] << 16), u[4] | (u[5] << 16), u[6] | (u[7] << 16));
+        } else {
+            o = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        }
+        out[idx] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" long long idv_lstm_ih_bf16_bytes(int H, int K) { return (long long)(8 * H / 32) * (K / 16) * 2 * 64 * 16; }
+
+extern "C" int idv_lstm_proj_bf16_supported(int H, int K) { return (H > 0 && K > 0 && (8 * H) % 256 == 0 && K % 64 == 0) ? 1 : 0; }
+
+extern "C" int idv_pack_lstm_ih_bf16(const float* w_ih_re, const float* w_ih_im, int H, int K, void* wfrag, void* stream) {
+    if (!w_ih_re || !w_ih_im || !wfrag || !idv_lstm_proj_bf16_supported(H, K)) return IDV_EINVAL;
+    const long long n = (long long)(8 * H / 32) * (K / 16) * 2 * 64;
+    long long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_lstm_ih_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w_ih_re, w_ih_im, H, K,
+                       (uint4*)wfrag);
+    return idv_launch_status();
+}
+
+extern "C" int idv_planar_to_kimage(const float* x, int nplanes, int J, int Jp, void* img, long long lo_off, void* stream) {
+    if (!x || !img || nplanes <= 0 || (nplanes % 8) || J <= 0 || Jp < J || (lo_off % 8) || (reinterpret_cast<uintptr_t>(img) & 15))
+        return IDV_EINVAL;
+    const long long n = (long long)(nplanes / 8) * Jp;
+    long long g = (n + 255) / 256;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(planar_to_kimage_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, nplanes, J, Jp,
+                       (unsigned short*)img, lo_off);
+    return idv_launch_status();
+}
+
+// G[part][(t, b)][8H] for part = real / imaginary input: the layer-0 input projection of idv_clstm_fwd (pass
+// flags bit 1 there to use it).  ximg: K-major image of the 2*K input planes (idv_planar_to_kimage).
+extern "C" int idv_lstm_proj_bf16x3(const void* ximg, long long lo_off_slots, int K, const void* wfrag_bf16, const float* bias,
+                                    float* G, int H, int B, int T, int Tp, int Jp, void* stream) {
+    if (!ximg || !wfrag_bf16 || !bias || !G || !idv_lstm_proj_bf16_supported(H, K) || B <= 0 || T <= 0 || Tp < T + 1 || Jp < B * Tp)
+        return IDV_EINVAL;
+    if (reinterpret_cast<uintptr_t>(ximg) & 15) return IDV_EINVAL;
+    PwBf16Args a{};
+    a.ximg = (const u32x4*)ximg; a.lo_off = lo_off_slots; a.KO = K / 8; a.part_stride = (long long)(K / 8) * Jp;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.t_valid = T; a.nB = B;
+    a.wfrag = (const uint4*)wfrag_bf16; a.bias = bias; a.out = G;
+    a.out_part_stride = (long long)T * B * 8 * H; a.ldo = 8 * H; a.M = 8 * H;
+    // fewest idle workgroup slots in the last round of 256
+    const long long mb = (a.M + 255) / 256;
+    auto eff = [&](int jt) { const long long n = ((a.J + jt - 1) / jt) * mb; return (double)n / (double)(((n + 255) / 256) * 256); };
+    hipStream_t st = (hipStream_t)stream;
+    return eff(64) > eff(128) + 0.02 ? launch_pw<2, 2>(a, st) : launch_pw<4, 2>(a, st);
+}

@@ -357,7 +357,13 @@ def pack_lstm(sd_get, H: int, K: int, layer: int, device):
          p(wih), p(bih), stream_ptr())
     whh = torch.empty(4 * 4 * H * H, dtype=torch.float32, device=device)
     call("idv_pack_lstm_hh", p(g(f"lstm_re.weight_hh_l{l}")), p(g(f"lstm_im.weight_hh_l{l}")), i(H), p(whh), stream_ptr())
-    return wih, bih, whh
+    wih16 = None
+    if layer == 0 and L.lib().idv_lstm_proj_bf16_supported(i(H), i(K)):
+        L.lib().idv_lstm_ih_bf16_bytes.restype = L._L
+        wih16 = torch.empty(int(L.lib().idv_lstm_ih_bf16_bytes(i(H), i(K))), dtype=torch.uint8, device=device)
+        call("idv_pack_lstm_ih_bf16", p(g(f"lstm_re.weight_ih_l{l}")), p(g(f"lstm_im.weight_ih_l{l}")), i(H), i(K), p(wih16),
+             stream_ptr())
+    return wih, bih, whh, wih16
 
 
 def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
@@ -366,9 +372,20 @@ def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
     out = Planar.empty(H, 1, x.B, x.T, x.Tp, x.buf.device)
     nwork = L.lib().idv_clstm_work_floats(i(H), i(x.B), i(x.T), i(x.Jp))
     work = torch.empty(bucket(int(nwork)), dtype=torch.float32, device=x.buf.device)
+    flags = 1 if PRECISION == "bf16x3" else 0
+    if flags and packed0[3] is not None:
+        # layer-0 input projection on the bf16 MFMA: K-major split image of the 2K input planes, then G into `work`
+        plane = 2 * K // 8 * x.Jp * 8
+        lo_off = plane + IMG_SLACK
+        kimg = torch.empty(bucket(2 * IMG_SLACK + lo_off + plane), dtype=torch.int16, device=x.buf.device)
+        kptr = L._P(kimg.data_ptr() + 2 * IMG_SLACK)
+        call("idv_planar_to_kimage", x.ptr(), i(2 * K), i(x.B * x.Tp), i(x.Jp), kptr, ll(lo_off), stream_ptr())
+        call("idv_lstm_proj_bf16x3", kptr, ll(lo_off // 8), i(K), p(packed0[3]), p(packed0[1]), p(work), i(H), i(x.B), i(x.T),
+             i(x.Tp), i(x.Jp), stream_ptr())
+        flags |= 2
+        _keep = kimg
     call("idv_clstm_fwd", x.ptr(), i(K), p(packed0[0]), p(packed0[1]), p(packed0[2]), p(packed1[0]), p(packed1[1]),
-         p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), i(1 if PRECISION == "bf16x3" else 0),
-         stream_ptr())
+         p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), i(flags), stream_ptr())
     return out
 
 

@@ -175,6 +175,19 @@ int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, c
                   const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp, float* work, float* out,
                   int flags, void* stream);
 
+/* Split-precision (bf16x3) form of the layer-0 input projection inside idv_clstm_fwd (nn.LSTM weight_ih_l0 of
+ * lstm_re / lstm_im applied to the real / imaginary input, complex_progress.py:50-74): ximg = K-major split image of
+ * the 2*K input planes (idv_planar_to_kimage: octet o = planes 8o..8o+7, layout as "split image" with F = 1),
+ * wfrag from idv_pack_lstm_ih_bf16 (idv_lstm_ih_bf16_bytes), bias = bih0 of idv_pack_lstm_ih, G = the first
+ * 16*T*B*H floats of idv_clstm_fwd's work buffer; then call idv_clstm_fwd with flags bit 1 set.  Needs
+ * 8H % 256 == 0 and K % 64 == 0 (idv_lstm_proj_bf16_supported). */
+long long idv_lstm_ih_bf16_bytes(int H, int K);
+int idv_lstm_proj_bf16_supported(int H, int K);
+int idv_pack_lstm_ih_bf16(const float* w_ih_re, const float* w_ih_im, int H, int K, void* wfrag, void* stream);
+int idv_planar_to_kimage(const float* x, int nplanes, int J, int Jp, void* img, long long lo_off_elems, void* stream);
+int idv_lstm_proj_bf16x3(const void* ximg, long long lo_off_slots, int K, const void* wfrag_bf16, const float* bias, float* G,
+                         int H, int B, int T, int Tp, int Jp, void* stream);
+
 /* reparameterization (pvae_module.py:1832-1886) with the two randn draws supplied by the caller.
  * lat: planar LSTM output [2][Hl][Jp]; miu/log_sigma/delta are channel offsets off_miu/off_ls/off_dl
  * (zdim channels each).  eps_r/eps_i: [B][ns][T][zdim].  z: planar [2][zdim][Jpz], columns (b*ns+s)*Tp+tp. */
