@@ -246,8 +246,8 @@ def main():
 
     # dominant kernel: group conv launches by kernel instantiation, HIP-event durations on the launch stream
     def kernel_name(cfg_id):
-        if cfg_id == -99:
-            return "(anonymous namespace)::ctconv_c1_bf16_kernel(CgemmArgs)"
+        if cfg_id in (-99, -98):
+            return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
         if cfg_id > 0:
             d = str(cfg_id)
             mode, t = (1 if len(d) == 7 else 0), d[-6:]

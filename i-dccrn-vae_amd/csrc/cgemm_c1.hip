@@ -17,13 +17,17 @@ constexpr int C1_JC = 2;        // 32-column tiles per row
 constexpr int C1_JT = 32 * C1_JC;
 constexpr int C1_PS = C1_JT + 8;
 constexpr int C1_PS4 = C1_PS / 4;
-constexpr int C1_IMG = C1_ROWS * 2 * C1_PS * 8;     // bf16 elements of one image (hi or lo), 16 channels
+constexpr int C1_SLOTS = C1_ROWS * 2 * C1_PS;       // 16-byte slots (row, octet, column) of one image
+constexpr int C1_NLDI = (C1_SLOTS + 255) / 256;     // image-source staging: slots per thread
+constexpr int C1_IMG = C1_NLDI * 256 * 8;           // bf16 elements of one image (hi or lo), padded to whole staging rounds
 constexpr int C1_BUF = 2 * C1_IMG;
 constexpr int C1_NTASK = C1_ROWS * C1_PS4 * 2;
 constexpr int C1_NLD = (C1_NTASK + 255) / 256;
 constexpr int C1_TILES = C1_ROWS * C1_JC;           // 20
 constexpr int C1_TPW = C1_TILES / 4;                // tiles per wave
 
+// IMGIN: sources are split images, staged by LDS-DMA in linear slot order (as cgemm_bf16.hip)
+template <bool IMGIN>
 __global__ __launch_bounds__(256, 1) void ctconv_c1_bf16_kernel(const CgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -41,12 +45,53 @@ __global__ __launch_bounds__(256, 1) void ctconv_c1_bf16_kernel(const CgemmArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-    // ---- staging (identical scheme to cgemm_bf16.hip) -------------------------------------------------
-    f32x4 stg[C1_NLD][8];
+    // ---- image-source staging ---------------------------------------------------------------------------
+    int ioff[IMGIN ? C1_NLDI : 1];
+    unsigned iok = 0;
+    if (IMGIN) {
+#pragma unroll
+        for (int i = 0; i < C1_NLDI; ++i) {
+            const int t = tid + i * 256;
+            const int fr = t / (2 * C1_PS), rem = t - fr * (2 * C1_PS);
+            const int oct = rem / C1_PS, col = rem - oct * C1_PS;
+            const int fi = fbase + fr;
+            iok |= ((fr < C1_ROWS && fi >= 0 && fi < a.Fin) ? 1u : 0u) << i;
+            ioff[i] = (oct * a.Fin + fi) * a.Jp + (j0 - 4 + col);
+        }
+    }
+    auto stage_dma = [&](int chunk, unsigned short* dst, int i_lo, int i_hi) {
+        const int ci0 = chunk * 8;
+        const u32x4* xh;
+        long long lo;
+        int zoff;
+        if (ci0 < a.C0) {
+            const int o0 = (ci0 / 4) * a.Fin * a.Jp;
+            xh = (const u32x4*)a.x0 + o0; lo = a.lo_off0; zoff = IDV_IMG_ZSLOT - o0;
+        } else {
+            const int o1 = ((ci0 - a.C0) / 4) * a.Fin * a.Jp;
+            xh = (const u32x4*)a.x1 + o1; lo = a.lo_off1; zoff = IDV_IMG_ZSLOT - o1;
+        }
+        typedef __attribute__((address_space(3))) unsigned short lds_u16;
+        const unsigned l0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u16*)(dst + (size_t)wave * 64 * 8));
+#pragma unroll
+        for (int i = 0; i < C1_NLDI; ++i) {
+            if (i < i_lo || i >= i_hi) continue;
+            const int o = ((iok >> i) & 1u) ? ioff[i] : zoff;
+            const u32x4* gh = xh + o;
+            const u32x4* gl = gh + lo;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(gh), "s"(l0 + (unsigned)(i * 256 * 16)) : "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(gl), "s"(l0 + (unsigned)(i * 256 * 16 + C1_IMG * 2)) : "memory");
+        }
+    };
+
+    // ---- planar staging (identical scheme to cgemm_bf16.hip) ---------------------------------------------
+    f32x4 stg[IMGIN ? 1 : C1_NLD][8];
     unsigned voff[C1_NLD];
     unsigned okbits = 0;
 #pragma unroll
-    for (int i = 0; i < C1_NLD; ++i) {
+    for (int i = 0; i < (IMGIN ? 0 : C1_NLD); ++i) {
         const int e = tid + i * 256;
         const int oct = e & 1, rest = e >> 1;
         const int fr = rest / C1_PS4, c4 = rest - fr * C1_PS4;
@@ -61,6 +106,7 @@ __global__ __launch_bounds__(256, 1) void ctconv_c1_bf16_kernel(const CgemmArgs 
         voff[i] = bits ? (unsigned)((4 * oct * a.Fin + fi) * a.Jp + jv) : 0u;
     }
     auto stage_load = [&](int chunk) {
+        if (IMGIN) return;
         const int ci0 = chunk * 8;
         const float* base;
         unsigned ristride, chstride;
@@ -84,6 +130,7 @@ __global__ __launch_bounds__(256, 1) void ctconv_c1_bf16_kernel(const CgemmArgs 
         }
     };
     auto stage_store = [&](unsigned short* dst) {
+        if (IMGIN) return;
 #pragma unroll
         for (int i = 0; i < C1_NLD; ++i) {
             const int e = tid + i * 256;
@@ -130,6 +177,7 @@ __global__ __launch_bounds__(256, 1) void ctconv_c1_bf16_kernel(const CgemmArgs 
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) cb[kt] = l31 + 4 - kt;          // transposed conv: tap kt reads x[t - kt]
 
+    if (IMGIN) stage_dma(0, smem16, 0, C1_NLDI);
     stage_load(0);
     load_a(0, a_cur);
     stage_store(smem16);
@@ -138,6 +186,7 @@ __global__ __launch_bounds__(256, 1) void ctconv_c1_bf16_kernel(const CgemmArgs 
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp)
             asm volatile("" : "+v"(a_cur[kt][sp].x), "+v"(a_cur[kt][sp].y), "+v"(a_cur[kt][sp].z), "+v"(a_cur[kt][sp].w));
+    if (IMGIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -149,6 +198,7 @@ __global__ __launch_bounds__(256, 1) void ctconv_c1_bf16_kernel(const CgemmArgs 
         for (int ti = 0; ti < C1_TPW; ++ti) {
             const int t = wave + 4 * ti;
             const int row = t / C1_JC, jc = t - row * C1_JC;
+            if (IMGIN) stage_dma(nxt, smem16 + ((chunk + 1) & 1) * C1_BUF, (ti * C1_NLDI) / C1_TPW, ((ti + 1) * C1_NLDI) / C1_TPW);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 const unsigned short* src = P + ((size_t)((row * 2 + half) * C1_PS + cb[kt] + jc * 32) * 8);
@@ -168,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void ctconv_c1_bf16_kernel(const CgemmArgs 
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) a_cur[kt][sp] = a_nxt[kt][sp];
+        if (IMGIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -237,6 +288,19 @@ __global__ void pack_c1_bf16_kernel(const float* __restrict__ w_re, const float*
 
 }  // namespace
 
+template <bool IMGIN>
+static int launch_c1(const CgemmArgs& a, hipStream_t st) {
+    constexpr size_t smem = (size_t)2 * C1_BUF * sizeof(unsigned short);
+    static_assert(smem >= (size_t)C1_ROWS * 10 * C1_JT * sizeof(float), "P exchange fits in the patch buffers");
+    auto k = ctconv_c1_bf16_kernel<IMGIN>;
+    if (smem > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return IDV_ELAUNCH;
+    dim3 grid((a.J + C1_JT - 1) / C1_JT, (a.Fin + C1_FI - 1) / C1_FI);
+    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, a);
+    return idv_launch_status();
+}
+
 extern "C" long long idv_ctconv_c1_wfrag_bytes(int cin_used) { return (2LL * cin_used / 16) * 2 * 2 * 64 * 16; }
 
 extern "C" int idv_pack_ctconv_c1_bf16(const float* w_re, const float* w_im, const float* fold, int Cin_total, int Cin_used,
@@ -260,13 +324,23 @@ extern "C" int idv_ctconv_c1_bf16x3_fwd(const float* x0, int C0, const float* x1
     a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.Jp1 = Jp1; a.x1_div = 1;
     a.wfrag = (const float*)wfrag; a.bias = bias; a.slope = prelu_slope; a.out = out;
     a.M = 2; a.Cout = 1; a.t_valid = t_valid_out; a.tshift = -1; a.nB = B;
-    constexpr size_t smem = (size_t)2 * C1_BUF * sizeof(unsigned short);
-    static_assert(smem >= (size_t)C1_ROWS * 10 * C1_JT * sizeof(float), "P exchange fits in the patch buffers");
-    auto k = ctconv_c1_bf16_kernel;
-    if (smem > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-        return IDV_ELAUNCH;
-    dim3 grid((a.J + C1_JT - 1) / C1_JT, (Fin + C1_FI - 1) / C1_FI);
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, (hipStream_t)stream, a);
-    return idv_launch_status();
+    return launch_c1<false>(a, (hipStream_t)stream);
+}
+
+// the same block with split-image sources (hi plane at the pointer, lo plane lo_off 16-byte slots further); planar output
+extern "C" int idv_ctconv_c1_img_fwd(const void* x0_img, long long lo_off0, int C0, const void* x1_img, long long lo_off1,
+                                     int C1, const void* wfrag, const float* bias, const float* prelu_slope, float* out,
+                                     int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream) {
+    if (!x0_img || !wfrag || !bias || !out || C0 <= 0 || (C0 % 8) || (C1 % 8) || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    if (C1 > 0 && (!x1_img || (reinterpret_cast<uintptr_t>(x1_img) & 15))) return IDV_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x0_img) & 15) || Jp < B * Tp) return IDV_EINVAL;
+    if ((long long)((2 * (C0 > C1 ? C0 : C1) + 7) / 8) * Fin * Jp > 0x7fffff00LL) return IDV_EINVAL;
+    CgemmArgs a{};
+    a.x0 = (const float*)x0_img; a.x1 = (const float*)x1_img; a.C0 = C0; a.C1 = C1;
+    a.lo_off0 = lo_off0; a.lo_off1 = lo_off1;
+    a.Fin = Fin; a.Fout = 2 * Fin - 1;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.Jp1 = Jp; a.x1_div = 1;
+    a.wfrag = (const float*)wfrag; a.bias = bias; a.slope = prelu_slope; a.out = out;
+    a.M = 2; a.Cout = 1; a.t_valid = t_valid_out; a.tshift = -1; a.nB = B;
+    return launch_c1<true>(a, (hipStream_t)stream);
 }

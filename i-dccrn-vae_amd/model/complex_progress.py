@@ -110,6 +110,15 @@ class _ComplexConvBase(nn.Module):
         return self._cache_bf16.get((re.weight, im.weight, fold), cin_used, lambda: ops.pack_cconv_bf16(
             re.weight.detach(), im.weight.detach(), fold, cin_used, self._transposed))
 
+    def _c1_path(self, c0: int, c1: int, stats=None, skip_div: int = 1) -> bool:
+        return (ops.PRECISION == "bf16x3" and self._transposed and self._causal and self.out_channel == 1 and stats is None
+                and skip_div == 1 and c0 % 8 == 0 and c1 % 8 == 0)
+
+    def takes_images(self, c0: int, c1: int) -> bool:
+        """Eval bf16x3: can this block read split-image sources directly (no conversion)?"""
+        return self._c1_path(c0, c1) or (ops.PRECISION == "bf16x3" and self.out_channel % 4 == 0
+                                        and ops.bf16_supported(self._transposed, c0, c1, 1, self.out_channel))
+
     def forward_planar(self, x, *, skip=None, skip_div: int = 1, fold=None, slope=None,
                        stats=None, zero_skip: bool = False, want: str = "planar"):
         """x / skip: Planar or ops.Image.  want: "planar" -> Planar, "image" -> ops.Image, "both" -> (Planar, Image).
@@ -122,6 +131,14 @@ class _ComplexConvBase(nn.Module):
         wbf = None
         c1 = skip.C if skip is not None else 0
         any_img = isinstance(x, ops.Image) or isinstance(skip, ops.Image)
+        if any_img and want == "planar" and self._c1_path(x.C, c1, stats, skip_div):
+            # single-output-channel block: image sources, planar result
+            x = x if isinstance(x, ops.Image) else ops.to_image(x)
+            skip = skip if (skip is None or isinstance(skip, ops.Image)) else ops.to_image(skip)
+            re, im = self._re, self._im
+            wc1 = self._cache_c1.get((re.weight, im.weight, fold), cin_used, lambda: ops.pack_ctconv_c1(
+                re.weight.detach(), im.weight.detach(), fold, cin_used))
+            return ops.ctconv_c1(x, wc1, bias, slope=slope, skip=skip)
         if any_img or want != "planar":
             img_ok = (ops.PRECISION == "bf16x3" and stats is None and skip_div == 1 and self.out_channel % 4 == 0
                       and ops.bf16_supported(self._transposed, x.C, c1, 1, self.out_channel))
@@ -144,8 +161,7 @@ class _ComplexConvBase(nn.Module):
             outp = self.forward_planar(x, skip=skip, skip_div=skip_div, fold=fold, slope=slope, stats=stats,
                                        zero_skip=zero_skip)
             return outp if want == "planar" else (ops.to_image(outp) if want == "image" else (outp, ops.to_image(outp)))
-        if (ops.PRECISION == "bf16x3" and self._transposed and self._causal and self.out_channel == 1 and stats is None
-                and skip_div == 1 and x.C % 8 == 0 and c1 % 8 == 0):
+        if self._c1_path(x.C, c1, stats, skip_div):
             re, im = self._re, self._im
             wc1 = self._cache_c1.get((re.weight, im.weight, fold), cin_used, lambda: ops.pack_ctconv_c1(
                 re.weight.detach(), im.weight.detach(), fold, cin_used))

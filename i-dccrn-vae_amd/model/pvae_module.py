@@ -215,7 +215,9 @@ class standard_DCCRN(nn.Module):
             last = i == n - 1
             nxt_needs_planar = last                                 # LSTM projection reads planar fp32
             dec_i = n - 1 - i                                       # decoder that takes this output as its skip
-            skip_planar = dec_i in self.skip_to_use and self.decoders[dec_i].transconv.out_channel % 4 != 0
+            dtc = self.decoders[dec_i].transconv
+            skip_planar = dec_i in self.skip_to_use and not dtc.takes_images(dtc.in_channel - enc.conv.out_channel,
+                                                                             enc.conv.out_channel)
             if nxt_needs_planar or skip_planar:
                 want = "both"
             else:
@@ -239,7 +241,8 @@ class standard_DCCRN(nn.Module):
         nd = len(self.decoders)
         for i, dec in enumerate(self.decoders):
             nxt = self.decoders[i + 1].transconv if i + 1 < nd else None
-            want = "image" if (nxt is not None and nxt.out_channel % 4 == 0) else "planar"
+            c_out = dec.transconv.out_channel
+            want = "image" if (nxt is not None and nxt.takes_images(c_out, nxt.in_channel - c_out)) else "planar"
             p = dec.forward_planar(p, False, skip=skips[n - 1 - i] if i in self.skip_to_use else None, want=want)
         return p
 

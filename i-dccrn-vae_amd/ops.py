@@ -200,20 +200,27 @@ def pack_ctconv_c1(w_re, w_im, fold, cin_used: Optional[int] = None):
     return wfrag
 
 
-def ctconv_c1(x: Planar, wfrag_c1, bias, *, slope=None, skip: Optional[Planar] = None) -> Planar:
-    """Causal / non-causal transposed conv with one output channel on the split-bf16 path."""
+def ctconv_c1(x, wfrag_c1, bias, *, slope=None, skip=None) -> Planar:
+    """Causal transposed conv with one output channel on the split-bf16 path; x / skip both Planar or both Image."""
     out = Planar.empty(1, 2 * x.F - 1, x.B, x.T, x.Tp, x.buf.device)
     c1 = skip.C if skip is not None else 0
     if LAUNCH_LOG is not None:
         macs = 4 * (x.C + c1) * 10 * x.B * x.T * x.F
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    call("idv_ctconv_c1_bf16x3_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
-         i(skip.Jp if skip is not None else 0), p(wfrag_c1), p(bias), p(slope), out.ptr(), i(x.F), i(x.B), i(x.Tp), i(x.Jp),
-         i(x.T), stream_ptr())
+    if isinstance(x, Image):
+        if skip is not None and not isinstance(skip, Image):
+            raise RuntimeError("ctconv_c1: x and skip must have the same format")
+        call("idv_ctconv_c1_img_fwd", x.ptr(), ll(x.lo_slots), i(x.C), skip.ptr() if skip is not None else p(None),
+             ll(skip.lo_slots if skip is not None else 0), i(c1), p(wfrag_c1), p(bias), p(slope), out.ptr(), i(x.F), i(x.B),
+             i(x.Tp), i(x.Jp), i(x.T), stream_ptr())
+    else:
+        call("idv_ctconv_c1_bf16x3_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
+             i(skip.Jp if skip is not None else 0), p(wfrag_c1), p(bias), p(slope), out.ptr(), i(x.F), i(x.B), i(x.Tp), i(x.Jp),
+             i(x.T), stream_ptr())
     if LAUNCH_LOG is not None:
         ev1.record()
-        LAUNCH_LOG.append((-99, macs, ev0, ev1))
+        LAUNCH_LOG.append((-98 if isinstance(x, Image) else -99, macs, ev0, ev1))
     return out
 
 

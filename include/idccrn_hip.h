@@ -129,6 +129,9 @@ int idv_pack_ctconv_c1_bf16(const float* w_re, const float* w_im, const float* f
 int idv_ctconv_c1_bf16x3_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, const void* wfrag,
                              const float* bias, const float* prelu_slope, float* out, int Fin, int B, int Tp, int Jp,
                              int t_valid_out, void* stream);
+int idv_ctconv_c1_img_fwd(const void* x0_img, long long lo_off0_slots, int C0, const void* x1_img, long long lo_off1_slots,
+                          int C1, const void* wfrag, const float* bias, const float* prelu_slope, float* out, int Fin, int B,
+                          int Tp, int Jp, int t_valid_out, void* stream);   /* same block, split-image sources */
 
 /* out[m][j] = bias[m] + sum_k w[m][k] x[k][j] over K planes of stride Jp: ComplexDense.forward
  * (complex_progress.py:83-89, one call per real/imag linear), the LSTM input projections, and the

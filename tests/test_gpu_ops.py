@@ -517,3 +517,8 @@ def test_ctconv_c1_bf16x3(ops, cin, skip_c, F, T, B):
     assert got.shape == want.shape
     assert relerr(got, want) < 2e-4
     assert float(y.planes()[..., 0].abs().max()) == 0.0 and float(y.planes()[..., y.T + 1:].abs().max()) == 0.0
+    # split-image sources: same operand split, identical result
+    yi = ops.ctconv_c1(ops.to_image(xp), wc1, bias, slope=torch.tensor([0.25], device=dev),
+                       skip=ops.to_image(skp) if skp is not None else None)
+    assert torch.equal(yi.tensor5(), y.tensor5())
+    assert float(yi.planes()[..., 0].abs().max()) == 0.0
