@@ -34,8 +34,10 @@ constexpr int PW_SO = 8;      // octets (of 8 k) per stage
 constexpr int PW_MW = 2;      // feature tiles per wave
 constexpr int PW_RING = 4;    // weight ring depth in k blocks (= k blocks per stage)
 
-template <int JC, int NP>
-__global__ __launch_bounds__(256, 1) void pw_bf16_swap_kernel(const PwBf16Args a) {
+// SWAP: transposed store (LSTM gates, see above).  !SWAP: MFMA roles as in the conv kernels (A = weights), planar
+// output out[m][Jp] with guard columns zeroed -- the DFT / inverse DFT of STFT / ISTFT and ComplexDense.
+template <int JC, int NP, bool SWAP>
+__global__ __launch_bounds__(256, 1) void pw_bf16_kernel(const PwBf16Args a) {
     constexpr int JT = 32 * JC;
     constexpr int NSLOT = NP * PW_SO * JT;           // 16-byte slots per stage image (hi or lo)
     constexpr int NLD = NSLOT / 256;
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(256, 1) void pw_bf16_swap_kernel(const PwBf16Args a
         }
     };
 
+    const bool live = mt0 * 32 < a.M;                  // waves whose feature tiles are all padding only stage and sync
     stage_dma(0, smem16, 0, NLD);
 #pragma unroll
     for (int d = 0; d < PW_RING - 1; ++d) load_w(d, w_hi[d], w_lo[d]);
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256, 1) void pw_bf16_swap_kernel(const PwBf16Args a
             // spread the next patch's copy and the weight prefetch over the stage (see cgemm_bf16.hip)
             stage_dma(nxt, Pn, (q * NLD) / (PW_SO / 2), ((q + 1) * NLD) / (PW_SO / 2));
             load_w(stage * (PW_SO / 2) + q + PW_RING - 1, w_hi[(q + PW_RING - 1) % PW_RING], w_lo[(q + PW_RING - 1) % PW_RING]);
+            if (live)
 #pragma unroll
             for (int p = 0; p < NP; ++p)
 #pragma unroll
@@ -133,9 +137,15 @@ __global__ __launch_bounds__(256, 1) void pw_bf16_swap_kernel(const PwBf16Args a
                         const bf16x8 wh = __builtin_bit_cast(bf16x8, w_hi[q % PW_RING][i]);
                         const bf16x8 wl = __builtin_bit_cast(bf16x8, w_lo[q % PW_RING][i]);
                         f32x16 c = acc[p][jc][i];
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, c, 0, 0, 0);
+                        if (SWAP) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, c, 0, 0, 0);
+                        } else {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, c, 0, 0, 0);
+                        }
                         acc[p][jc][i] = c;
                     }
                 }
@@ -147,6 +157,28 @@ __global__ __launch_bounds__(256, 1) void pw_bf16_swap_kernel(const PwBf16Args a
         __syncthreads();
     }
 
+    if (!SWAP) {
+        // ---- epilogue, planar: lanes run along j, registers along m -> out[part][m][Jp], guard columns zero
+#pragma unroll
+        for (int i = 0; i < PW_MW; ++i)
+#pragma unroll
+            for (int jc = 0; jc < JC; ++jc) {
+                const int j = j0 + jc * 32 + l31;
+                if (j >= a.J) continue;
+                const int tp = j % a.Tp;
+                const bool keep = (tp >= 1) && (tp <= a.t_valid);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (mt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m >= a.M) continue;
+                    const float bm = a.bias ? a.bias[m] : 0.f;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        a.out[(size_t)p * a.out_part_stride + (size_t)m * a.Jp + j] = keep ? acc[p][jc][i][r] + bm : 0.f;
+                }
+            }
+        return;
+    }
     // ---- epilogue: registers run along j, lanes along m -> out[part][(tp-1)*B + b][m]
 #pragma unroll
     for (int i = 0; i < PW_MW; ++i) {
@@ -168,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void pw_bf16_swap_kernel(const PwBf16Args a
     }
 }
 
-template <int JC, int NP>
+template <int JC, int NP, bool SWAP>
 int launch_pw(const PwBf16Args& a0, hipStream_t st) {
     constexpr int JT = 32 * JC;
     constexpr size_t smem = (size_t)2 * 2 * NP * PW_SO * JT * 16;
@@ -177,15 +209,15 @@ int launch_pw(const PwBf16Args& a0, hipStream_t st) {
     a.jtiles = (a.J + JT - 1) / JT;
     a.mblocks = (a.M + 255) / 256;
     const long long nblk = (long long)((a.jtiles + 7) / 8) * 8 * a.mblocks;
-    auto k = pw_bf16_swap_kernel<JC, NP>;
+    auto k = pw_bf16_kernel<JC, NP, SWAP>;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return IDV_ELAUNCH;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), smem, st, a);
     return idv_launch_status();
 }
 
 // one thread: one (octet, j) slot = 8 consecutive planes
-__global__ void planar_to_kimage_kernel(const float* __restrict__ x, int nplanes, int J, int Jp, unsigned short* __restrict__ img,
-                                        long long lo_off) {
+__global__ void planar_to_kimage_kernel(const float* __restrict__ x, int nvalid, int nplanes, int J, int Jp,
+                                        unsigned short* __restrict__ img, long long lo_off) {
     const long long n = (long long)(nplanes / 8) * Jp;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(idx % Jp);
@@ -195,8 +227,8 @@ __global__ void planar_to_kimage_kernel(const float* __restrict__ x, int nplanes
         for (int w = 0; w < 4; ++w) {
             float x0 = 0.f, x1 = 0.f;
             if (j < J) {
-                x0 = x[(size_t)(8 * o + 2 * w) * Jp + j];
-                x1 = x[(size_t)(8 * o + 2 * w + 1) * Jp + j];
+                if (8 * o + 2 * w < nvalid) x0 = x[(size_t)(8 * o + 2 * w) * Jp + j];
+                if (8 * o + 2 * w + 1 < nvalid) x1 = x[(size_t)(8 * o + 2 * w + 1) * Jp + j];
             }
             const unsigned u0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u;
             const unsigned u1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
@@ -256,13 +288,14 @@ extern "C" int idv_pack_lstm_ih_bf16(const float* w_ih_re, const float* w_ih_im,
     return idv_launch_status();
 }
 
-extern "C" int idv_planar_to_kimage(const float* x, int nplanes, int J, int Jp, void* img, long long lo_off, void* stream) {
-    if (!x || !img || nplanes <= 0 || (nplanes % 8) || J <= 0 || Jp < J || (lo_off % 8) || (reinterpret_cast<uintptr_t>(img) & 15))
+// nplanes: planes of the image (a multiple of 8); planes >= nvalid are written as zeros (K padding)
+extern "C" int idv_planar_to_kimage(const float* x, int nvalid, int nplanes, int J, int Jp, void* img, long long lo_off, void* stream) {
+    if (!x || !img || nplanes <= 0 || (nplanes % 8) || nvalid <= 0 || nvalid > nplanes || J <= 0 || Jp < J || (lo_off % 8) || (reinterpret_cast<uintptr_t>(img) & 15))
         return IDV_EINVAL;
     const long long n = (long long)(nplanes / 8) * Jp;
     long long g = (n + 255) / 256;
     if (g > 65536) g = 65536;
-    hipLaunchKernelGGL(planar_to_kimage_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, nplanes, J, Jp,
+    hipLaunchKernelGGL(planar_to_kimage_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, nvalid, nplanes, J, Jp,
                        (unsigned short*)img, lo_off);
     return idv_launch_status();
 }
@@ -283,5 +316,116 @@ extern "C" int idv_lstm_proj_bf16x3(const void* ximg, long long lo_off_slots, in
     const long long mb = (a.M + 255) / 256;
     auto eff = [&](int jt) { const long long n = ((a.J + jt - 1) / jt) * mb; return (double)n / (double)(((n + 255) / 256) * 256); };
     hipStream_t st = (hipStream_t)stream;
-    return eff(64) > eff(128) + 0.02 ? launch_pw<2, 2>(a, st) : launch_pw<4, 2>(a, st);
+    return eff(64) > eff(128) + 0.02 ? launch_pw<2, 2, true>(a, st) : launch_pw<4, 2, true>(a, st);
+}
+
+namespace {
+
+// generic [M][K] row-major fp32 -> fragments, K zero-padded to Kp (a multiple of 64), rows padded to 256
+__global__ void pack_pw_bf16_kernel(const float* __restrict__ w, int M, int K, int Kp, int Mtiles, uint4* __restrict__ out) {
+    const int NKB = Kp / 16;
+    const long long n = (long long)Mtiles * NKB * 2 * 64;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        long long t = idx >> 6;
+        const int split = (int)(t & 1); t >>= 1;
+        const int kb = (int)(t % NKB);
+        const int mt = (int)(t / NKB);
+        const int m = mt * 32 + (lane & 31);
+        unsigned u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * kb + 8 * (lane >> 5) + j;
+            const float v = (m < M && k < K) ? w[(size_t)m * K + k] : 0.f;
+            const unsigned hi = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
+            u[j] = split == 0 ? hi >> 16 : (pack_bf16(v - __builtin_bit_cast(float, hi), 0.f) & 0xffffu);
+        }
+        out[idx] = make_uint4(u[0] | (u[1] << 16), u[2] | (u[3] << 16), u[4] | (u[5] << 16), u[6] | (u[7] << 16));
+    }
+}
+
+// STFT framing straight into the K-major image: slot (octet o, column j) = samples 8o..8o+7 of frame j
+__global__ __launch_bounds__(256) void stft_frames_kimg_kernel(const float* __restrict__ x, int B, int L, int n_fft, int win,
+                                                               int hop, int T, unsigned short* __restrict__ img, long long lo_off,
+                                                               int KO, int Tp, int Jp) {
+    extern __shared__ float seg[];
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int left = (n_fft - win) / 2, half = n_fft / 2;
+    const int nt = min(32, T - t0);
+    const int seglen = hop * (nt - 1) + win;
+    const long long s0 = (long long)hop * t0 + left - half;
+    for (int e = threadIdx.x; e < seglen; e += blockDim.x) {
+        long long s = s0 + e;
+        if (s < 0) s = -s;
+        if (s >= L) s = 2LL * (L - 1) - s;
+        seg[e] = (s >= 0 && s < L) ? x[(size_t)b * L + s] : 0.f;
+    }
+    __syncthreads();
+    const int tl = threadIdx.x & 31;
+    // 33 columns per block: the 32 frames and, in the first block of an utterance, its guard column
+    for (int o = threadIdx.x >> 5; o < KO; o += 8) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool guard = pass == 1;
+            if (guard && (blockIdx.x != 0 || tl != 0)) continue;
+            if (!guard && tl >= nt) continue;
+            const size_t col = (size_t)b * Tp + (guard ? 0 : t0 + tl + 1);
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int k0 = 8 * o + 2 * w;
+                const float x0 = (!guard && k0 < win) ? seg[hop * tl + k0] : 0.f;
+                const float x1 = (!guard && k0 + 1 < win) ? seg[hop * tl + k0 + 1] : 0.f;
+                const unsigned u0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u;
+                const unsigned u1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
+                hw[w] = (u0 >> 16) | u1;
+                lw[w] = pack_bf16(x0 - __builtin_bit_cast(float, u0), x1 - __builtin_bit_cast(float, u1));
+            }
+            unsigned short* d = img + ((size_t)o * Jp + col) * 8;
+            *(uint4*)d = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            *(uint4*)(d + lo_off) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" long long idv_pw_bf16_wfrag_bytes(int M, int K) {
+    return (long long)((M + 255) / 256 * 8) * ((K + 63) / 64 * 4) * 2 * 64 * 16;
+}
+
+extern "C" int idv_pack_pw_bf16(const float* w, int M, int K, void* wfrag, void* stream) {
+    if (!w || !wfrag || M <= 0 || K <= 0) return IDV_EINVAL;
+    const int Kp = (K + 63) / 64 * 64, Mtiles = (M + 255) / 256 * 8;
+    const long long n = (long long)Mtiles * (Kp / 16) * 2 * 64;
+    long long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_pw_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, M, K, Kp, Mtiles, (uint4*)wfrag);
+    return idv_launch_status();
+}
+
+// out[m][Jp] (planar, guard columns zero) = sum_k W[m][k] * x[k][j] + bias[m]; ximg: K-major image with Kp/8 octets
+// (Kp = K rounded up to 64, the padding octets hold zeros or anything finite -- their weights are zero)
+extern "C" int idv_pw_bf16x3(const void* ximg, long long lo_off_slots, int K, const void* wfrag_bf16, const float* bias, float* out,
+                             int M, int B, int Tp, int Jp, int t_valid, void* stream) {
+    if (!ximg || !wfrag_bf16 || !out || K <= 0 || M <= 0 || B <= 0 || Tp <= 1 || Jp < B * Tp || (reinterpret_cast<uintptr_t>(ximg) & 15))
+        return IDV_EINVAL;
+    PwBf16Args a{};
+    const int Kp = (K + 63) / 64 * 64;
+    a.ximg = (const u32x4*)ximg; a.lo_off = lo_off_slots; a.KO = Kp / 8; a.part_stride = 0;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.t_valid = t_valid; a.nB = B;
+    a.wfrag = (const uint4*)wfrag_bf16; a.bias = bias; a.out = out; a.out_part_stride = 0; a.ldo = 0; a.M = M;
+    const long long mb = (M + 255) / 256;
+    auto eff = [&](int jt) { const long long n = ((a.J + jt - 1) / jt) * mb; return (double)n / (double)(((n + 255) / 256) * 256); };
+    hipStream_t st = (hipStream_t)stream;
+    return eff(64) > eff(128) + 0.02 ? launch_pw<2, 1, false>(a, st) : launch_pw<4, 1, false>(a, st);
+}
+
+extern "C" int idv_stft_frames_kimage(const float* x, int B, int L, int n_fft, int win, int hop, int T, void* img, long long lo_off,
+                                      int Tp, int Jp, void* stream) {
+    if (!x || !img || B <= 0 || L <= n_fft / 2 || T != 1 + L / hop || Tp < T + 1 || Jp < B * Tp || (lo_off % 8)) return IDV_EINVAL;
+    const int KO = (win + 63) / 64 * 8;
+    const size_t smem = (size_t)(hop * 31 + win) * sizeof(float);
+    hipLaunchKernelGGL(stft_frames_kimg_kernel, dim3((T + 31) / 32, B), dim3(256), smem, (hipStream_t)stream, x, B, L, n_fft, win,
+                       hop, T, (unsigned short*)img, lo_off, KO, Tp, Jp);
+    return idv_launch_status();
 }

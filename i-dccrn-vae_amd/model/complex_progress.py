@@ -314,7 +314,8 @@ class ComplexDense(nn.Module):
     def _packed(self):
         r, im = self.linear_read, self.linear_imag
         return self._cache.get((r.weight, r.bias, im.weight, im.bias), None, lambda: (
-            ops.pack_pw(r.weight.detach(), r.bias.detach()), ops.pack_pw(im.weight.detach(), im.bias.detach())))
+            ops.pack_pw(r.weight.detach(), r.bias.detach()) + (ops.pack_pw_bf16(r.weight.detach()),),
+            ops.pack_pw(im.weight.detach(), im.bias.detach()) + (ops.pack_pw_bf16(im.weight.detach()),)))
 
     def forward_planar(self, x: Planar, C_out: int, F_out: int) -> Planar:
         if x.C * x.F != self.in_channel or C_out * F_out != self.out_channel:

@@ -136,6 +136,46 @@ def to_planar(x: Image) -> Planar:
     return out
 
 
+class KImage:
+    """K-major split image  kimg[hi|lo][nplanes/8][Jp][8]  (octet o = planes 8o..8o+7): the activation operand of the
+    bf16x3 point-wise contractions (LSTM projection, DFT, dense)."""
+
+    __slots__ = ("buf", "nplanes", "Jp", "lo_off")
+
+    def __init__(self, nplanes: int, Jp: int, device):
+        assert nplanes % 8 == 0
+        plane = nplanes // 8 * Jp * 8
+        self.nplanes, self.Jp, self.lo_off = nplanes, Jp, plane + IMG_SLACK
+        self.buf = torch.empty(bucket(2 * IMG_SLACK + self.lo_off + plane), dtype=torch.int16, device=device)
+
+    def ptr(self, octet: int = 0):
+        return L._P(self.buf.data_ptr() + 2 * IMG_SLACK + 16 * octet * self.Jp)
+
+    @property
+    def lo_slots(self) -> int:
+        return self.lo_off // 8
+
+    @classmethod
+    def from_planes(cls, x_ptr, nvalid: int, J: int, Jp: int, device, pad_to: int = 8):
+        nplanes = (nvalid + pad_to - 1) // pad_to * pad_to
+        out = cls(nplanes, Jp, device)
+        call("idv_planar_to_kimage", x_ptr, i(nvalid), i(nplanes), i(J), i(Jp), out.ptr(), ll(out.lo_off), stream_ptr())
+        return out
+
+
+def pack_pw_bf16(w):
+    M, K = w.shape
+    L.lib().idv_pw_bf16_wfrag_bytes.restype = L._L
+    wf = torch.empty(int(L.lib().idv_pw_bf16_wfrag_bytes(i(M), i(K))), dtype=torch.uint8, device=w.device)
+    call("idv_pack_pw_bf16", p(w.contiguous()), i(M), i(K), p(wf), stream_ptr())
+    return wf
+
+
+def pw_bf16x3(kimg: KImage, octet0: int, K: int, wfrag16, bias, M: int, B: int, Tp: int, t_valid: int, out_ptr):
+    call("idv_pw_bf16x3", kimg.ptr(octet0), ll(kimg.lo_slots), i(K), p(wfrag16), p(bias), out_ptr, i(M), i(B), i(Tp), i(kimg.Jp),
+         i(t_valid), stream_ptr())
+
+
 def _dev_scratch(n: int, device, dtype=torch.float32, zero=False):
     return (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=device)
 
@@ -382,15 +422,10 @@ def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
     flags = 1 if PRECISION == "bf16x3" else 0
     if flags and packed0[3] is not None:
         # layer-0 input projection on the bf16 MFMA: K-major split image of the 2K input planes, then G into `work`
-        plane = 2 * K // 8 * x.Jp * 8
-        lo_off = plane + IMG_SLACK
-        kimg = torch.empty(bucket(2 * IMG_SLACK + lo_off + plane), dtype=torch.int16, device=x.buf.device)
-        kptr = L._P(kimg.data_ptr() + 2 * IMG_SLACK)
-        call("idv_planar_to_kimage", x.ptr(), i(2 * K), i(x.B * x.Tp), i(x.Jp), kptr, ll(lo_off), stream_ptr())
-        call("idv_lstm_proj_bf16x3", kptr, ll(lo_off // 8), i(K), p(packed0[3]), p(packed0[1]), p(work), i(H), i(x.B), i(x.T),
-             i(x.Tp), i(x.Jp), stream_ptr())
+        kimg = KImage.from_planes(x.ptr(), 2 * K, x.B * x.Tp, x.Jp, x.buf.device)
+        call("idv_lstm_proj_bf16x3", kimg.ptr(), ll(kimg.lo_slots), i(K), p(packed0[3]), p(packed0[1]), p(work), i(H), i(x.B),
+             i(x.T), i(x.Tp), i(x.Jp), stream_ptr())
         flags |= 2
-        _keep = kimg
     call("idv_clstm_fwd", x.ptr(), i(K), p(packed0[0]), p(packed0[1]), p(packed0[2]), p(packed1[0]), p(packed1[1]),
          p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), i(flags), stream_ptr())
     return out
@@ -400,8 +435,13 @@ def cdense(x: Planar, packed_r, packed_i, M: int, C_out: int, F_out: int) -> Pla
     """ComplexDense on a planar [2][K][Jp] activation -> planar [2][C_out][F_out][Jp] (M = C_out*F_out)."""
     K = x.C * x.F
     out = Planar.empty(C_out, F_out, x.B, x.T, x.Tp, x.buf.device)
-    for ri, (wf, bf) in enumerate((packed_r, packed_i)):
-        pw_gemm(x.ptr(ri * x.C), K, wf, bf, M, x.B, x.Tp, x.Jp, x.T, out.ptr(ri * C_out))
+    if PRECISION == "bf16x3" and K % 64 == 0 and len(packed_r) > 2 and packed_r[2] is not None:
+        kimg = KImage.from_planes(x.ptr(), 2 * K, x.B * x.Tp, x.Jp, x.buf.device)
+        for ri, pk in enumerate((packed_r, packed_i)):
+            pw_bf16x3(kimg, ri * K // 8, K, pk[2], pk[1], M, x.B, x.Tp, x.T, out.ptr(ri * C_out))
+        return out
+    for ri, pk in enumerate((packed_r, packed_i)):
+        pw_gemm(x.ptr(ri * x.C), K, pk[0], pk[1], M, x.B, x.Tp, x.Jp, x.T, out.ptr(ri * C_out))
     return out
 
 
@@ -418,6 +458,8 @@ class DftPlan:
         call("idv_make_dft", i(n_fft), i(win), i(hop), i(T), p(w_fwd), p(w_inv), p(self.env_inv), stream_ptr())
         self.fwd = pack_pw(w_fwd, None)
         self.inv = pack_pw(w_inv, None)
+        self.fwd16 = pack_pw_bf16(w_fwd)          # split-bf16 fragments of the same matrices (bf16x3 mode)
+        self.inv16 = pack_pw_bf16(w_inv)
 
 
 def stft(x: torch.Tensor, plan: DftPlan, Tp: Optional[int] = None) -> Planar:
@@ -427,6 +469,14 @@ def stft(x: torch.Tensor, plan: DftPlan, Tp: Optional[int] = None) -> Planar:
     assert T == plan.T, "DftPlan built for another length"
     Tp = Tp or T + 1
     x = x.contiguous()
+    if PRECISION == "bf16x3":
+        Jp = Planar.jp_for(B, Tp)
+        kimg = KImage((plan.win + 63) // 64 * 64, Jp, x.device)
+        call("idv_stft_frames_kimage", p(x), i(B), i(Lx), i(plan.n_fft), i(plan.win), i(plan.hop), i(T), kimg.ptr(),
+             ll(kimg.lo_off), i(Tp), i(Jp), stream_ptr())
+        out = Planar.empty(1, plan.F, B, T, Tp, x.device)
+        pw_bf16x3(kimg, 0, plan.win, plan.fwd16, None, 2 * plan.F, B, Tp, T, out.ptr())
+        return out
     fr = Planar.empty(1, plan.win // 2, B, T, Tp, x.device)      # [win][Jp] scratch (2*C*F = win planes)
     assert plan.win % 2 == 0
     call("idv_stft_frames", p(x), i(B), i(Lx), i(plan.n_fft), i(plan.win), i(plan.hop), i(T), fr.ptr(), i(Tp), i(fr.Jp),
@@ -440,7 +490,11 @@ def istft(spec: Planar, plan: DftPlan) -> torch.Tensor:
     """ISTFT.forward: planar [2][1][F][Jp] -> y [B, hop*(T-1)]."""
     B, T = spec.B, spec.T
     fr = Planar.empty(1, plan.win // 2, B, T, spec.Tp, spec.buf.device)
-    pw_gemm(spec.ptr(), 2 * plan.F, plan.inv[0], plan.inv[1], plan.win, B, spec.Tp, spec.Jp, T, fr.ptr())
+    if PRECISION == "bf16x3":
+        kimg = KImage.from_planes(spec.ptr(), 2 * plan.F, B * spec.Tp, spec.Jp, spec.buf.device, pad_to=64)
+        pw_bf16x3(kimg, 0, 2 * plan.F, plan.inv16, None, plan.win, B, spec.Tp, T, fr.ptr())
+    else:
+        pw_gemm(spec.ptr(), 2 * plan.F, plan.inv[0], plan.inv[1], plan.win, B, spec.Tp, spec.Jp, T, fr.ptr())
     y = torch.empty(B, plan.hop * (T - 1), dtype=torch.float32, device=spec.buf.device)
     call("idv_istft_ola", fr.ptr(), p(plan.env_inv), i(B), i(plan.n_fft), i(plan.win), i(plan.hop), i(T), i(spec.Tp),
          i(fr.Jp), p(y), stream_ptr())

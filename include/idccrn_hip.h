@@ -187,7 +187,18 @@ int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, c
 long long idv_lstm_ih_bf16_bytes(int H, int K);
 int idv_lstm_proj_bf16_supported(int H, int K);
 int idv_pack_lstm_ih_bf16(const float* w_ih_re, const float* w_ih_im, int H, int K, void* wfrag, void* stream);
-int idv_planar_to_kimage(const float* x, int nplanes, int J, int Jp, void* img, long long lo_off_elems, void* stream);
+int idv_planar_to_kimage(const float* x, int nvalid, int nplanes, int J, int Jp, void* img, long long lo_off_elems, void* stream);
+/* bf16x3 form of idv_pw_gemm (swap = 0): out[m][Jp] = sum_k W[m][k] x[k][j] + bias[m], guard columns zero -- the
+ * windowed DFT / inverse DFT of STFT.forward / ISTFT.forward (pvae_module.py:21-27, :38-42) and the two linears of
+ * ComplexDense (complex_progress.py:83-89).  ximg: K-major split image with K rounded up to 64 planes
+ * (idv_planar_to_kimage with nplanes = that, or idv_stft_frames_kimage = idv_stft_frames writing the image directly);
+ * wfrag: idv_pack_pw_bf16 of the row-major [M][K] matrix (idv_pw_bf16_wfrag_bytes). */
+long long idv_pw_bf16_wfrag_bytes(int M, int K);
+int idv_pack_pw_bf16(const float* w, int M, int K, void* wfrag, void* stream);
+int idv_pw_bf16x3(const void* ximg, long long lo_off_slots, int K, const void* wfrag_bf16, const float* bias, float* out, int M,
+                  int B, int Tp, int Jp, int t_valid, void* stream);
+int idv_stft_frames_kimage(const float* x, int B, int L, int n_fft, int win, int hop, int T, void* img, long long lo_off_elems,
+                           int Tp, int Jp, void* stream);
 int idv_lstm_proj_bf16x3(const void* ximg, long long lo_off_slots, int K, const void* wfrag_bf16, const float* bias, float* G,
                          int H, int B, int T, int Tp, int Jp, void* stream);
 

@@ -522,3 +522,40 @@ def test_ctconv_c1_bf16x3(ops, cin, skip_c, F, T, B):
                        skip=ops.to_image(skp) if skp is not None else None)
     assert torch.equal(yi.tensor5(), y.tensor5())
     assert float(yi.planes()[..., 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("L,B", [(3201, 3), (64000, 2)])
+def test_stft_istft_dense_bf16x3(ops, L, B):
+    """bf16x3 point-wise contractions (K-major split image + idv_pw_bf16x3): windowed DFT, inverse DFT and
+    ComplexDense against the oracle; frame indexing exact, guard columns zero, STFT -> ISTFT identity."""
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(B, L, generator=g) * 0.1
+    keep = ops.PRECISION
+    try:
+        ops.set_precision("bf16x3")
+        T = 1 + L // HOP
+        plan = ops.DftPlan(NFFT, WIN, HOP, T, "cuda")
+        X = ops.stft(x.cuda(), plan)
+        assert X.T == T and X.F == NFFT // 2 + 1
+        assert relerr(X.tensor4().cpu(), O.stft(x, NFFT, HOP, WIN)) < 2e-5
+        assert float(X.planes()[..., 0].abs().max()) == 0.0
+        y = ops.istft(X, plan).cpu()
+        assert y.shape[1] == HOP * (L // HOP)
+        assert relerr(y, x[:, :y.shape[1]]) < 2e-5
+        # dense 128 -> 1280 (the DCCRN bottleneck shape)
+        K, M, Td = 128, 1280, 37
+        xd = torch.randn(B, K, 1, Td, 2, generator=g)
+        wr, br = torch.randn(M, K, generator=g) * 0.1, torch.randn(M, generator=g)
+        wi, bi = torch.randn(M, K, generator=g) * 0.1, torch.randn(M, generator=g)
+        xp = ops.Planar.from_tensor5(xd.cuda())
+        pr = ops.pack_pw(wr.cuda(), br.cuda()) + (ops.pack_pw_bf16(wr.cuda()),)
+        pi = ops.pack_pw(wi.cuda(), bi.cuda()) + (ops.pack_pw_bf16(wi.cuda()),)
+        out = ops.cdense(xp, pr, pi, M, 256, 5)
+        got = out.tensor5().cpu()                                          # [B, 256, 5, T, 2]
+        xr, xi = xd[:, :, 0, :, 0].permute(0, 2, 1).double(), xd[:, :, 0, :, 1].permute(0, 2, 1).double()   # [B, T, K]
+        want_r = (xr @ wr.double().T + br.double()).reshape(B, Td, 256, 5).permute(0, 2, 3, 1)
+        want_i = (xi @ wi.double().T + bi.double()).reshape(B, Td, 256, 5).permute(0, 2, 3, 1)
+        assert relerr(got[..., 0], want_r.float()) < 2e-5 and relerr(got[..., 1], want_i.float()) < 2e-5
+        assert float(out.planes()[..., 0].abs().max()) == 0.0
+    finally:
+        ops.set_precision(keep)
