@@ -400,7 +400,7 @@ def test_image_path_matches_planar_path(ops, amd):
     keep = (ops.IMAGE_PATH, ops.PRECISION)
     try:
         ops.set_precision("bf16x3")
-        for base, L_, B in ((32, 3000, 3), (8, 2345, 2), (4, 1600, 2)):
+        for base, L_, B in ((32, 3000, 3), (32, 700, 1), (32, 16000, 5), (8, 2345, 2), (4, 1600, 2)):
             np_ = O.net_params(True, base)
             m = pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, [0, 1, 2, 3, 4, 5], "mask", False, None, None)
             m.load_state_dict(O.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 21))
