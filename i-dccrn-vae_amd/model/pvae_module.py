@@ -450,7 +450,18 @@ class _VAEDecoderBase(nn.Module):
         Bn = zp.B
         p = self.dense.forward_planar(zp, C, F)
         outs = []
+        # eval bf16x3 without real skips: the blocks hand split-bf16 images to each other (see standard_DCCRN)
+        images = (not train) and ops.PRECISION == "bf16x3" and ops.IMAGE_PATH and (pad == "zero" or not self.use_sc)
+        nd = len(self.decoders)
         for i, dec in enumerate(self.decoders):
+            if images:
+                zs = self.use_sc and i in self.skip_to_use
+                nxt = self.decoders[i + 1].transconv if i + 1 < nd else None
+                c_out = dec.transconv.out_channel
+                want = "image" if (nxt is not None and nxt.takes_images(c_out, 0)) else "planar"
+                p = dec.forward_planar(p, False, zero_skip=zs, want=want)
+                outs.append(p)
+                continue
             if self.use_sc and i in self.skip_to_use:
                 if pad == "zero":
                     p = dec.forward_planar(p, train, zero_skip=True)       # cat with zeros == half of K skipped
@@ -483,8 +494,14 @@ class pvae_dccrn_decoder_skip_prepare(_VAEDecoderBase):
         if self.recon_type != "real_imag":
             raise ValueError("pvae_dccrn_decoder_skip_prepare implements recon_type='real_imag' (as the reference)")
         recon, predict, outs = self._decode(stft_x, z, skiper, C, F, train, "zero")
-        self.decoder_outputs = [tag5(o) for o in outs]
+        self._decoder_outs = outs
         return recon, predict
+
+    @property
+    def decoder_outputs(self):
+        """Per-block outputs [B*ns, C, F, T, 2] (reference: self.decoder_outputs, pvae_module.py:2090,:2099); blocks that
+        handed a split image to the next one are decoded on access."""
+        return [tag5(o if isinstance(o, Planar) else ops.to_planar(o)) for o in getattr(self, "_decoder_outs", [])]
 
 
 class nsvae_pvae_dccrn_decoder_twophase(_VAEDecoderBase):

@@ -158,6 +158,39 @@ def test_cvae_golden(pm, losses, golden, tag):
     assert z2.shape == z.shape and torch.isfinite(z2).all()
 
 
+def test_cvae_decoder_image_path(pm):
+    """Full-width CVAE encoder -> decoder (zero skips) in bf16x3 eval: the decoder blocks hand split images to each
+    other; identical to the planar inter-layer path, decoder_outputs decoded on access, twophase pad='zero' too."""
+    ops = pm.ops
+    np_ = O.net_params(True, 32)
+    zdim, ns = 16, 2
+    enc = load_synth(pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns), 3)
+    dec = load_synth(pm.pvae_dccrn_decoder_skip_prepare(np_, True, "cuda", ns, zdim, NFFT, HOP, WIN, "real_imag", SKIP), 4)
+    dec2 = load_synth(pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, "cuda", ns, zdim, NFFT, HOP, WIN, "mask", True, SKIP, False), 5)
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(2, 2500, generator=g) * 0.1).cuda()
+    keep = (ops.IMAGE_PATH, ops.PRECISION)
+    try:
+        ops.set_precision("bf16x3")
+        eps = (torch.randn(2, ns, 26, zdim, generator=g).cuda(), torch.randn(2, ns, 26, zdim, generator=g).cuda())
+        z, miu, ls, dl, skiper, C, F, stft_x = enc(x, train=False, eps=eps)
+        res = {}
+        for flag in (True, False):
+            ops.IMAGE_PATH = flag
+            r1, p1 = dec(stft_x, z, skiper, C, F, train=False)
+            outs = [o.clone() for o in dec.decoder_outputs]
+            r2, p2 = dec2(stft_x, z, skiper, C, F, train=False, pad="zero")
+            res[flag] = (r1, torch.view_as_real(p1), r2, torch.view_as_real(p2), outs)
+        for a, b in zip(res[True][:4], res[False][:4]):
+            assert torch.equal(a, b)
+        assert len(res[True][4]) == 6
+        for a, b in zip(res[True][4], res[False][4]):
+            assert a.shape == b.shape and relerr(a, b) < 1e-5          # image-decoded (hi + lo) vs fp32 planar
+    finally:
+        ops.IMAGE_PATH = keep[0]
+        ops.set_precision(keep[1])
+
+
 @pytest.mark.parametrize("tag", ["mini_eval", "mini_train"])
 def test_nsvae_twophase_golden(pm, losses, golden, tag):
     d = golden("vae_nsvae_" + tag)
