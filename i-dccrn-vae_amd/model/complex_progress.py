@@ -50,14 +50,22 @@ class _PackCache:
     def __init__(self):
         self.key = None
         self.val = None
+        self.ready = None
 
     def get(self, tensors, extra, build):
         key = tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (extra,)
         if key != self.key:
             self.val = build()
             self.key = key
-            # the pack kernels ran on the current stream; later users may be on another one (sub-batch streams)
-            torch.cuda.current_stream().synchronize()
+            # the pack kernels ran on the current stream; later users may be on another one (sub-batch streams):
+            # they wait on this event on the device, the host never blocks
+            self.ready = torch.cuda.Event()
+            self.ready.record()
+        elif self.ready is not None:
+            if self.ready.query():
+                self.ready = None                       # packed long ago: nothing to order any more
+            else:
+                torch.cuda.current_stream().wait_event(self.ready)
         return self.val
 
 
