@@ -85,10 +85,12 @@ def build_workload(name, B, device, rank):
         se = synth_state(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, device, zdim, NFFT, HOP, WIN, ns, 2), 56).to(device)
         loss = nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.0, zdim, ns, 2, 'original', 'False', SKIP, 'both')
 
+        ops = importlib.import_module("i-dccrn-vae_amd").ops
+
         def step():
-            c = ce(clean, train=False)
-            n = ne(noise, train=False)
-            s = se(noisy, train=False)
+            # three independent encoders: one HIP stream each (their H = 384 / 768 recurrences are latency-bound)
+            c, n, s = ops.concurrent([lambda: ce(clean, train=False), lambda: ne(noise, train=False),
+                                      lambda: se(noisy, train=False)], device)
             return loss.final_nsvae_loss(c[1], n[1], s[1], s[5], c[2], n[2], s[2], s[6], c[3], n[3], s[3], s[7],
                                          s[0], s[4], c[4], n[4], s[8])[0]
         return step, B, {"workload": "NSVAE: 2 frozen CVAE/NVAE encoders + noisy encoder (latent_num=2) + nsvae KL loss",

@@ -303,6 +303,26 @@ def side_streams(n: int, device):
     return pool[:n]
 
 
+def concurrent(fns, device=None):
+    """Run independent callables (e.g. the frozen clean / noise encoders and the noisy encoder of the NSVAE step) on
+    separate HIP streams and join: their latency-bound phases (the per-step recurrences) overlap.  Results may be
+    used on the current stream afterwards; they return to their stream's pool, whose next use through this function
+    starts behind everything enqueued on the current stream until then."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    main = torch.cuda.current_stream(device)
+    streams = side_streams(len(fns), device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    outs = []
+    for fn, st in zip(fns, streams):
+        st.wait_event(ready)
+        with torch.cuda.stream(st):
+            outs.append(fn())
+    for st in streams:
+        main.wait_stream(st)
+    return outs
+
+
 def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True, slope=None, skip: Optional[Planar] = None,
             skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None,
             wfrag_bf16: Optional[torch.Tensor] = None, image: str = ""):
