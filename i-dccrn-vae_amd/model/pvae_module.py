@@ -451,15 +451,29 @@ class _VAEDecoderBase(nn.Module):
         p = self.dense.forward_planar(zp, C, F)
         outs = []
         # eval bf16x3 without real skips: the blocks hand split-bf16 images to each other (see standard_DCCRN)
-        images = (not train) and ops.PRECISION == "bf16x3" and ops.IMAGE_PATH and (pad == "zero" or not self.use_sc)
+        images = (not train) and ops.PRECISION == "bf16x3" and ops.IMAGE_PATH
+        if pad not in ("zero", "sig"):
+            raise ValueError(f"pad {pad!r}")
         nd = len(self.decoders)
         for i, dec in enumerate(self.decoders):
             if images:
-                zs = self.use_sc and i in self.skip_to_use
+                has_skip = self.use_sc and i in self.skip_to_use
+                sk = None
+                if has_skip and pad == "sig":
+                    # repeated skips: materialise the repeat once (a copy of <= 2 x 22 MB per utterance) so the block
+                    # runs on the split-image kernels instead of the exact-fp32 scalar-staged path
+                    sk = planar_of(skiper[len(skiper) - 1 - i], zp.Tp)
+                    if Bn % sk.B:
+                        raise RuntimeError("batch of z is not a multiple of the skip batch")
+                    if Bn != sk.B:
+                        sk = ops.repeat_batch(sk, Bn // sk.B)
                 nxt = self.decoders[i + 1].transconv if i + 1 < nd else None
                 c_out = dec.transconv.out_channel
-                want = "image" if (nxt is not None and nxt.takes_images(c_out, 0)) else "planar"
-                p = dec.forward_planar(p, False, zero_skip=zs, want=want)
+                nxt_skip = 0
+                if nxt is not None and pad == "sig" and self.use_sc and (i + 1) in self.skip_to_use:
+                    nxt_skip = nxt.in_channel - c_out
+                want = "image" if (nxt is not None and nxt.takes_images(c_out, nxt_skip)) else "planar"
+                p = dec.forward_planar(p, False, skip=sk, zero_skip=has_skip and pad == "zero", want=want)
                 outs.append(p)
                 continue
             if self.use_sc and i in self.skip_to_use:

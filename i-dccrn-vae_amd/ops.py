@@ -303,6 +303,16 @@ def side_streams(n: int, device):
     return pool[:n]
 
 
+def repeat_batch(x: Planar, n: int) -> Planar:
+    """Each utterance n times in a row (`skip.repeat_interleave(n, 0)`, reference pvae_module.py:2563-2567) as a new
+    planar buffer, so the repeated-skip decoder can use the kernels that take x1_div == 1 sources (bf16x3 / images)."""
+    out = Planar.empty(x.C, x.F, x.B * n, x.T, x.Tp, x.buf.device)
+    dst = torch.as_strided(out.buf, (2, x.C, x.F, x.B, n, x.Tp),
+                           (x.C * x.F * out.Jp, x.F * out.Jp, out.Jp, n * x.Tp, x.Tp, 1), SLACK)
+    dst.copy_(x.planes().unsqueeze(4).expand(2, x.C, x.F, x.B, n, x.Tp))      # planes(): [2, C, F, B, Tp]
+    return out
+
+
 def concurrent(fns, device=None):
     """Run independent callables (e.g. the frozen clean / noise encoders and the noisy encoder of the NSVAE step) on
     separate HIP streams and join: their latency-bound phases (the per-step recurrences) overlap.  Results may be

@@ -180,9 +180,12 @@ def test_cvae_decoder_image_path(pm):
             r1, p1 = dec(stft_x, z, skiper, C, F, train=False)
             outs = [o.clone() for o in dec.decoder_outputs]
             r2, p2 = dec2(stft_x, z, skiper, C, F, train=False, pad="zero")
-            res[flag] = (r1, torch.view_as_real(p1), r2, torch.view_as_real(p2), outs)
+            r3, _ = dec2(stft_x, z, skiper, C, F, train=False, pad="sig")
+            res[flag] = (r1, torch.view_as_real(p1), r2, torch.view_as_real(p2), outs, r3)
         for a, b in zip(res[True][:4], res[False][:4]):
             assert torch.equal(a, b)
+        # repeated real skips: images + materialised repeat vs the exact-fp32 x1_div kernel
+        assert relerr(res[True][5], res[False][5]) < 1e-4
         assert len(res[True][4]) == 6
         for a, b in zip(res[True][4], res[False][4]):
             assert a.shape == b.shape and relerr(a, b) < 1e-5          # image-decoded (hi + lo) vs fp32 planar
