@@ -156,9 +156,16 @@ def _build_decoders(net_params, causal, skip_to_use, use_sc=True) -> nn.ModuleLi
 
 def _run_encoders(encoders, x: Planar, train: bool) -> List[Planar]:
     outs = []
-    for enc in encoders:
-        x = enc.forward_planar(x, train)
-        outs.append(x)
+    images = (not train) and ops.PRECISION == "bf16x3" and ops.IMAGE_PATH
+    for i, enc in enumerate(encoders):
+        nxt = encoders[i + 1].conv if i + 1 < len(encoders) else None
+        if images and nxt is not None and nxt.takes_images(enc.conv.out_channel, 0):
+            # eval bf16x3: the planar output is what the caller gets (skiper), the split image feeds the next block
+            p, x = enc.forward_planar(x, False, want="both")
+            outs.append(p)
+        else:
+            x = enc.forward_planar(x, train)
+            outs.append(x)
     return outs
 
 
