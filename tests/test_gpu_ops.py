@@ -559,3 +559,49 @@ def test_stft_istft_dense_bf16x3(ops, L, B):
         assert float(out.planes()[..., 0].abs().max()) == 0.0
     finally:
         ops.set_precision(keep)
+
+
+@pytest.mark.parametrize("precision,B,T,cin,cout,F", [("fp32", 3, 50, 64, 32, 17), ("bf16x3", 3, 50, 64, 32, 17),
+                                                      ("bf16x3", 16, 641, 256, 128, 9)])
+def test_conv_adjoint_identity(ops, precision, B, T, cin, cout, F):
+    """Size-independent property (no oracle): the causal transposed conv y = A x and the non-causal conv with the
+    conjugate-transposed weights are adjoint, <A x, y> = <x, A* y>, and A is linear -- checked through the C ABI at
+    a full-size decoder shape as well.  (A* is also the data gradient the backward row will use.)"""
+    g = torch.Generator().manual_seed(5)
+    dev = "cuda"
+    wr, wi = torch.randn(cin, cout, 5, 2, generator=g) * 0.05, torch.randn(cin, cout, 5, 2, generator=g) * 0.05
+    zb_o, zb_i = torch.zeros(cout), torch.zeros(cin)
+    x = torch.randn(B, cin, F, T, 2, generator=g)
+    x[:, :, :, T - 1] = 0.0                       # the non-causal conv yields frames 0 .. T-2
+    x2 = torch.randn(B, cin, F, T, 2, generator=g)
+    x2[:, :, :, T - 1] = 0.0
+    y = torch.randn(B, cout, 2 * F - 1, T, 2, generator=g)
+    Tp = T + 1
+    xp, x2p, yp = (ops.Planar.from_tensor5(t.to(dev), Tp) for t in (x, x2, y))
+    wfA, bA = ops.pack_cconv(wr.to(dev), wi.to(dev), zb_o.to(dev), zb_o.to(dev), None, transposed=True)
+    # A*: conv weights [Cout' = cin][Cin' = cout] = the transposed-conv tensor itself, imaginary part negated
+    wfT, bT = ops.pack_cconv(wr.to(dev), (-wi).to(dev), zb_i.to(dev), zb_i.to(dev), None, transposed=False)
+    keep = ops.PRECISION
+    try:
+        ops.set_precision(precision)
+        kwA = dict(transposed=True, causal=True)
+        kwT = dict(transposed=False, causal=False)
+        if precision == "bf16x3":
+            kwA["wfrag_bf16"] = ops.pack_cconv_bf16(wr.to(dev), wi.to(dev), None, transposed=True)
+            kwT["wfrag_bf16"] = ops.pack_cconv_bf16(wr.to(dev), (-wi).to(dev), None, transposed=False)
+        Ax = ops.cconv2d(xp, wfA, bA, cout, **kwA)
+        Ax2 = ops.cconv2d(x2p, wfA, bA, cout, **kwA)
+        Aty = ops.cconv2d(yp, wfT, bT, cin, **kwT)
+        assert Aty.T == T - 1 and Ax.T == T
+        lhs = float((Ax.tensor5().double() * y.to(dev).double()).sum())
+        rhs = float((Aty.tensor5().double() * x[:, :, :, :T - 1].to(dev).double()).sum())
+        scale = float(Ax.tensor5().double().norm() * y.double().norm())
+        tol = 1e-6 if precision == "fp32" else 2e-5
+        assert abs(lhs - rhs) < tol * scale, (lhs, rhs, scale)
+        # linearity: A(x + 2 x2) = A x + 2 A x2
+        xs = ops.Planar.from_tensor5((x + 2 * x2).to(dev), Tp)
+        Axs = ops.cconv2d(xs, wfA, bA, cout, **kwA)
+        want = Ax.tensor5() + 2 * Ax2.tensor5()
+        assert relerr(Axs.tensor5(), want) < (2e-6 if precision == "fp32" else 2e-5)
+    finally:
+        ops.set_precision(keep)
