@@ -264,7 +264,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((FO_T == 3 && JC_W == 1 && MT_W == 1)
     int cbase[2];                                           // column of this lane for time tap kt
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-        const int toff = (MODE == IDV_CONV) ? kt + a.tshift : -kt;
+        // transposed conv: tshift -1 = taps (x[t], x[t-1]) (the forward block); 0 = taps (x[t+1], x[t]), the adjoint of
+        // the causal conv
+        const int toff = (MODE == IDV_CONV) ? kt + a.tshift : a.tshift + 1 - kt;
         cbase[kt] = wn * (JC_W * 32) + l31 + 4 + toff;
     }
     auto load_b = [&](const unsigned short* P, int fr, int kt, uint4 (&bh)[JC_W], uint4 (&bl)[JC_W]) {

@@ -335,7 +335,7 @@ def concurrent(fns, device=None):
 
 def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True, slope=None, skip: Optional[Planar] = None,
             skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None,
-            wfrag_bf16: Optional[torch.Tensor] = None, image: str = ""):
+            wfrag_bf16: Optional[torch.Tensor] = None, image: str = "", adjoint_time: bool = False):
     """(causal_)ComplexConv2d / (causal_)ComplexConvTranspose2d forward on planar activations.
     image="also" / "only": the exact-fp32 kernel additionally / only writes a split-bf16 image -> (Planar|None, Image)."""
     Fout = 2 * x.F - 1 if transposed else (x.F - 1) // 2 + 1
@@ -344,6 +344,11 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
     else:
         t_out = x.T + 1 if transposed else x.T - 1
     tshift = -1 if (causal or transposed) else 0
+    if adjoint_time:
+        # transposed conv reading (x[t+1], x[t]): with conjugate-transposed weights the adjoint (data gradient) of
+        # the causal conv; all T frames are produced (x[T] is the next utterance's zero guard column)
+        assert transposed and causal
+        tshift = 0
     if out is None and image != "only":
         out = Planar.empty(cout, Fout, x.B, t_out, x.Tp, x.buf.device)
     c1 = skip.C if skip is not None else 0

@@ -76,7 +76,10 @@ int idv_make_dft(int n_fft, int win, int hop, int T, float* w_fwd, float* w_inv,
  * folded eval BatchNorm and PReLU (pvae_module.py:64-68, :88-93) when prelu_slope != NULL, and with
  * the train-mode moment sums (complex_progress.py:132-143) when stats != NULL (stats: [Cout][5]
  * doubles, zeroed by the caller: sum r, i, r*r, i*i, r*i over kept positions).
- * tshift: -1 causal conv / any transposed conv, 0 non-causal conv.  t_valid_out: frames kept. */
+ * tshift: -1 causal conv (taps x[t-1], x[t]) / any transposed conv of the model (taps x[t], x[t-1]); 0 non-causal conv
+ * (taps x[t], x[t+1]); a transposed conv with tshift 0 reads (x[t+1], x[t]) -- with conjugate-transposed weights the
+ * adjoint (data gradient) of the causal conv, as the non-causal conv is of the transposed conv (tests:
+ * test_conv_adjoint_identity).  t_valid_out: frames kept. */
 int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const float* wfrag,
                     const float* bias, const float* prelu_slope, float* out, double* stats, int transposed,
                     int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);

@@ -598,6 +598,25 @@ def test_conv_adjoint_identity(ops, precision, B, T, cin, cout, F):
         scale = float(Ax.tensor5().double().norm() * y.double().norm())
         tol = 1e-6 if precision == "fp32" else 2e-5
         assert abs(lhs - rhs) < tol * scale, (lhs, rhs, scale)
+        # the other pair: causal conv C (encoder block) and the transposed conv reading (x[t+1], x[t]) with the
+        # conjugate-transposed weights.  conv weight [cout2][cin2] = the tensor above read as [cin][cout]
+        cw_r, cw_i = wr, wi                                               # conv: Cout2 = cin, Cin2 = cout
+        u = torch.randn(B, cout, 2 * F - 1, T, 2, generator=g)            # conv input  [B, Cin2, 2F-1, T]
+        v = torch.randn(B, cin, F, T, 2, generator=g)                     # conv output [B, Cout2, F, T]
+        up, vp = ops.Planar.from_tensor5(u.to(dev), Tp), ops.Planar.from_tensor5(v.to(dev), Tp)
+        wfC, bC = ops.pack_cconv(cw_r.to(dev), cw_i.to(dev), zb_i.to(dev), zb_i.to(dev), None, transposed=False)
+        wfCt, bCt = ops.pack_cconv(cw_r.to(dev), (-cw_i).to(dev), zb_o.to(dev), zb_o.to(dev), None, transposed=True)
+        kwC, kwCt = dict(transposed=False, causal=True), dict(transposed=True, causal=True, adjoint_time=True)
+        if precision == "bf16x3":
+            kwC["wfrag_bf16"] = ops.pack_cconv_bf16(cw_r.to(dev), cw_i.to(dev), None, transposed=False)
+            kwCt["wfrag_bf16"] = ops.pack_cconv_bf16(cw_r.to(dev), (-cw_i).to(dev), None, transposed=True)
+        Cu = ops.cconv2d(up, wfC, bC, cin, **kwC)
+        Ctv = ops.cconv2d(vp, wfCt, bCt, cout, **kwCt)
+        assert Cu.T == T and Ctv.T == T and Ctv.F == 2 * F - 1
+        lhs2 = float((Cu.tensor5().double() * v.to(dev).double()).sum())
+        rhs2 = float((Ctv.tensor5().double() * u.to(dev).double()).sum())
+        scale2 = float(Cu.tensor5().double().norm() * v.double().norm())
+        assert abs(lhs2 - rhs2) < tol * scale2, (lhs2, rhs2, scale2)
         # linearity: A(x + 2 x2) = A x + 2 A x2
         xs = ops.Planar.from_tensor5((x + 2 * x2).to(dev), Tp)
         Axs = ops.cconv2d(xs, wfA, bA, cout, **kwA)
