@@ -30,6 +30,7 @@ NFFT, HOP, WIN, LEN = 512, 100, 400, 64000
 SKIP = [0, 1, 2, 3, 4, 5]
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak (2:1-sparsity figures never used)
+DEFAULT_BATCH = 128      # utterances per GPU per step (single stream: 1711 / 1797 / 1817 / 1858 utt/s at 64 / 96 / 128 / 192)
 METRIC = "4s@16kHz utterances/sec fwd+SI-SNR, DCCRN-CL, 1/2/4/8 MI355X vs host CPU"
 
 
@@ -161,7 +162,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="utterances per GPU per step")
     ap.add_argument("--workload", default="dccrn_cl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default=os.environ.get("IDV_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
@@ -282,7 +283,7 @@ def main():
         ach = 2 * macs / secs / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and args.batch == 64 and args.workload == "dccrn_cl":      # serial-pass launches (B=64)
+        if os.path.exists(tpath) and args.batch == DEFAULT_BATCH and args.workload == "dccrn_cl" and n_streams == 1:
             tk = json.load(open(tpath))["kernels"].get(kernel_name(dom))
             if tk:
                 traffic = tk["hbm_bytes_per_launch"]
@@ -290,7 +291,7 @@ def main():
             "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic,
             "traffic_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from the committed rocprofv3 --pmc passes "
-                            "(profiles/r01_traffic.json, same command, B=64); null when the run differs from that command",
+                            "(profiles/r01_traffic.json, same command and batch); null when the run differs from that command",
             "peak_note": ("dense bf16 MFMA peak; achieved counts ALGORITHMIC fp32 flops (4 real convs), the kernel executes 3 bf16 "
                           "MFMA products per algorithmic product" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
             "kernel": kernel_name(dom), "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
