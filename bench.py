@@ -30,7 +30,7 @@ NFFT, HOP, WIN, LEN = 512, 100, 400, 64000
 SKIP = [0, 1, 2, 3, 4, 5]
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA peak (2:1-sparsity figures never used)
-DEFAULT_BATCH = 128      # utterances per GPU per step (single stream: 1711 / 1797 / 1817 / 1858 utt/s at 64 / 96 / 128 / 192)
+DEFAULT_BATCH = 64       # utterances per GPU per step
 METRIC = "4s@16kHz utterances/sec fwd+SI-SNR, DCCRN-CL, 1/2/4/8 MI355X vs host CPU"
 
 
@@ -283,7 +283,7 @@ def main():
         ach = 2 * macs / secs / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and args.batch == DEFAULT_BATCH and args.workload == "dccrn_cl" and n_streams == 1:
+        if os.path.exists(tpath) and args.batch == DEFAULT_BATCH and args.workload == "dccrn_cl":     # single-stream launches
             tk = json.load(open(tpath))["kernels"].get(kernel_name(dom))
             if tk:
                 traffic = tk["hbm_bytes_per_launch"]

@@ -281,12 +281,11 @@ def pack_pw(w, bias):
 LAUNCH_LOG = None
 
 # Eval-mode sub-batch pipelining (model/pvae_module.py DCCRN_.forward): number of HIP streams a batch is split over.
-# OFF by default (1).  With two concurrently executing hardware queues a full-size forward (B = 64) showed sparse,
-# run-to-run varying wrong elements (~0.04 % of the mask output, up to 6 % of the waveform peak) although every
-# kernel is bit-exact on one queue, alone on two queues with persistent buffers, and with the same split executed
-# on one stream; not root-caused yet, so concurrency is opt-in: IDV_STREAM_SPLIT=2.
-STREAM_SPLIT = int(os.environ.get("IDV_STREAM_SPLIT", "1"))
-CONCURRENT = os.environ.get("IDV_CONCURRENT", "0") != "0"      # ops.concurrent really uses several streams
+# Concurrent queues are only safe because the library is built without packed-fp32 VALU code (__graft_entry__.build,
+# -fno-slp-vectorize): on MI355X v_pk_fma_f32 / v_pk_mul_f32 results of one kernel came out wrong in 16-lane slices
+# while an MFMA-saturating kernel of another stream shared its SIMDs.
+STREAM_SPLIT = int(os.environ.get("IDV_STREAM_SPLIT", "2"))
+CONCURRENT = os.environ.get("IDV_CONCURRENT", "1") != "0"      # ops.concurrent really uses several streams
 STREAM_STAGGER = os.environ.get("IDV_STREAM_STAGGER", "1") != "0"   # part k+1 starts when part k reaches its LSTM
 STREAM_STAGGER_BELOW = 64                        # measured: staggering pays for parts of < 64 utterances (B=64: +4.5 %), not above
 STREAM_SPLIT_MIN_BATCH = 16                      # per-stream utterances below which launch overhead dominates

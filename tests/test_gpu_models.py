@@ -158,6 +158,35 @@ def test_cvae_golden(pm, losses, golden, tag):
     assert z2.shape == z.shape and torch.isfinite(z2).all()
 
 
+def test_two_streams_full_size_bit_exact(pm):
+    """Full-width DCCRN-CL, 4 s utterances: the forward on two concurrent HIP streams is bit-identical to the
+    one-stream forward, run after run.  (Regression test for the packed-fp32 corruption under concurrent MFMA kernels:
+    with v_pk_*_f32 code in the library ~0.04 % of the mask elements came out wrong)"""
+    ops = pm.ops
+    np_ = O.net_params(True, 32)
+    m = load_synth(pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None), 6)
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(32, 64000, generator=g) * 0.1).cuda()
+    keep = (ops.STREAM_SPLIT, ops.PRECISION, ops.IMAGE_PATH)
+    try:
+        ops.set_precision("bf16x3")
+        ops.IMAGE_PATH = True
+        ops.STREAM_SPLIT = 1
+        ref, pref = m(x, train=False)
+        ref = ref.clone()
+        ops.STREAM_SPLIT = 2
+        assert ops.stream_split(32) == 2
+        for _ in range(8):
+            est, p = m(x, train=False)
+            assert torch.equal(est, ref)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.view_as_real(p), torch.view_as_real(pref))
+    finally:
+        ops.STREAM_SPLIT = keep[0]
+        ops.set_precision(keep[1])
+        ops.IMAGE_PATH = keep[2]
+
+
 def test_cvae_decoder_image_path(pm):
     """Full-width CVAE encoder -> decoder (zero skips) in bf16x3 eval: the decoder blocks hand split images to each
     other; identical to the planar inter-layer path, decoder_outputs decoded on access, twophase pad='zero' too."""
