@@ -11,10 +11,10 @@ import sys
 src = sys.argv[1]
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
-for name in ("stats_default", "stats_2stream"):
+for name in ("stats_default", "stats_single"):
     for f in glob.glob(os.path.join(src, name, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, f"kernel_stats_{name[6:]}.csv"))
-for name in ("bench_default.json", "bench_2stream.json"):
+for name in ("bench_default.json", "bench_single.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 
 
@@ -39,7 +39,7 @@ for k in fetch:
                   "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
 json.dump({
     "source": "profiles/tools/collect.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
-              "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (default: one stream, B = 128, bf16x3)",
+              "IDV_STREAM_SPLIT=1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline; B = 64, bf16x3",
     "correction": "FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE doubled for gfx950 wide coalesced (16 B/lane) reads "
                   "per MI355X_MICROARCH.md section HBM",
     "kernels": kernels}, open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
