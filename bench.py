@@ -312,6 +312,9 @@ def main():
                 "achieved": round(2 * om / osec / 1e12, 3), "frac": round(2 * om / osec / 1e12 / peak, 4),
                 "note": "event intervals on each sub-batch stream; they include CU time-slicing with the other stream"}
         if split:
+            roofline["clock_note"] = ("committed counters (profiles/r01h: GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES): the conv kernels run "
+                                      "power-limited at 1.65-1.80 GHz and the MFMA pipe is busy 65-78 % of those cycles; `peak` is the "
+                                      "dense bf16 rate at the nominal 2.4 GHz")
             roofline["executed_bf16_tflops"] = round(3 * ach, 1)
             roofline["frac_executed"] = round(3 * ach / peak, 4)
             roofline["vs_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 3)
