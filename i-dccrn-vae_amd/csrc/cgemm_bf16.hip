@@ -151,9 +151,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((FO_T == 3 && JC_W == 1 && MT_W == 1)
             const u32x4* gh = xh + o;
             const u32x4* gl = gh + lo;
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         :: "v"(gh), "s"(l0 + (unsigned)(i * NT * 16)) : "memory");
+                         :: "v"(gh), "s"(l0 + (unsigned)(i * NT * 16)) : "memory", "m0");
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         :: "v"(gl), "s"(l0 + (unsigned)(i * NT * 16 + IMG * 2)) : "memory");
+                         :: "v"(gl), "s"(l0 + (unsigned)(i * NT * 16 + IMG * 2)) : "memory", "m0");
         }
     };
     auto stage_store_img = [&](unsigned short* dst) {

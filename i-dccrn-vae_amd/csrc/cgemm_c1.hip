@@ -80,9 +80,9 @@ __global__ __launch_bounds__(256, 1) void ctconv_c1_bf16_kernel(const CgemmArgs 
             const u32x4* gh = xh + o;
             const u32x4* gl = gh + lo;
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         :: "v"(gh), "s"(l0 + (unsigned)(i * 256 * 16)) : "memory");
+                         :: "v"(gh), "s"(l0 + (unsigned)(i * 256 * 16)) : "memory", "m0");
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         :: "v"(gl), "s"(l0 + (unsigned)(i * 256 * 16 + C1_IMG * 2)) : "memory");
+                         :: "v"(gl), "s"(l0 + (unsigned)(i * 256 * 16 + C1_IMG * 2)) : "memory", "m0");
         }
     };
 

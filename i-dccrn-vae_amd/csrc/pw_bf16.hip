@@ -89,9 +89,9 @@ __global__ __launch_bounds__(256, 1) void pw_bf16_kernel(const PwBf16Args a) {
             const u32x4* gh = xh + soff[i];
             const u32x4* gl = gh + a.lo_off;
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         :: "v"(gh), "s"(l0 + (unsigned)(i * 256 * 16)) : "memory");
+                         :: "v"(gh), "s"(l0 + (unsigned)(i * 256 * 16)) : "memory", "m0");
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         :: "v"(gl), "s"(l0 + (unsigned)(i * 256 * 16 + IMG * 2)) : "memory");
+                         :: "v"(gl), "s"(l0 + (unsigned)(i * 256 * 16 + IMG * 2)) : "memory", "m0");
         }
     };
 

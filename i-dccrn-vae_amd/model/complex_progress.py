@@ -228,6 +228,7 @@ class ComplexBatchNormal(nn.Module):
         self.dis_cbn = dis_cbn
         self.C = C
         self._cache = _PackCache()
+        self._stats_gen = 0         # bumped whenever a kernel rewrites the running buffers through raw pointers
 
     def _affine(self):
         return [t.detach() for t in (self.gamma_rr, self.gamma_ri, self.gamma_ii, self.beta_r, self.beta_i)]
@@ -240,7 +241,9 @@ class ComplexBatchNormal(nn.Module):
         def build():
             mom = torch.stack([b.detach().reshape(-1) for b in bufs]).contiguous()
             return ops.cbn_fold(mom, *self._affine())
-        return self._cache.get(tensors, None, build)
+        # idv_cbn_finalize updates the running buffers in place behind torch's back (no _version bump), so the
+        # generation counter is part of the key; the conv pack caches key on this fold tensor and follow it
+        return self._cache.get(tensors, self._stats_gen, build)
 
     def finish_train(self, act: Planar, stats: torch.Tensor, slope=None):
         """stats (moment sums from the conv epilogue or idv_cbn_stats) -> running buffers, normalise
@@ -249,6 +252,7 @@ class ComplexBatchNormal(nn.Module):
         if not all(b.is_contiguous() for b in (self.running_mean_real, self.running_mean_imag, self.Vrr, self.Vri, self.Vii)):
             raise RuntimeError("ComplexBatchNormal running buffers must be contiguous")
         ops.cbn_train(act, stats, self, slope, first_call=first, momentum=self.momentum)
+        self._stats_gen += 1
         if first and not self.dis_cbn:
             self.init_flag = False
         return act

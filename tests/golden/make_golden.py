@@ -333,6 +333,224 @@ def gen_vae(tag, base, zdim, B, L, ns, seed, train):
          seed=seed, base=base, zdim=zdim, ns=ns, train=int(train))
 
 
+# ----------------------------------------------------------------------------- gradients (reference autograd)
+def summarize(t, limit=16384, cap=8192):
+    """Full tensor when small, otherwise a strided subsample; the consumer re-derives the stride from the shapes."""
+    t = t.detach().reshape(-1)
+    if t.numel() <= limit:
+        return t.clone()
+    stride = -(-t.numel() // cap)
+    return t[::stride].clone()
+
+
+def grad_record(out, prefix, module):
+    """Per parameter: summarised gradient + its L2 norm (norm catches errors outside the subsample)."""
+    for k, p_ in module.named_parameters():
+        if p_.grad is None:
+            continue
+        out[f"g:{prefix}{k}"] = summarize(p_.grad)
+        out[f"n:{prefix}{k}"] = p_.grad.double().norm()
+
+
+def adam_record(out, prefix, module, lr=1e-3, wd=1e-3):
+    """One Adam step as the reference trainers take it (supervised_dccrn/train.py:109, :243): updated weights."""
+    params = [p_ for p_ in module.parameters() if p_.grad is not None]
+    opt = torch.optim.Adam(params, lr=lr, weight_decay=wd)
+    opt.step()
+    for k, p_ in module.named_parameters():
+        if p_.grad is not None and (k.endswith("conv_re.weight") or k.endswith("gamma_ri") or k.endswith("prelu.weight")
+                                    or k.endswith("weight_hh_l1") or k.endswith("linear_read.weight")
+                                    or k.endswith("tconv_im.weight")):
+            out[f"a:{prefix}{k}"] = summarize(p_)
+
+
+def gen_grad_dccrn(tag, base, B, L, seed, weights):
+    print(f"== grads DCCRN_ {tag}: base={base} B={B} L={L} weights={weights}")
+    np_ = O.net_params(True, base)
+    skip = [0, 1, 2, 3, 4, 5]
+    with torch.enable_grad():
+        m = R_pm.DCCRN_(NFFT, HOP, np_, True, "cpu", WIN, skip, "mask", False, None, None)
+        load_synth(m, seed)
+        m.train()
+        fix_bn_flags(m, True)
+        x = rnd(seed + 100, B, L, scale=0.1).requires_grad_(True)
+        clean_ref = rnd(seed + 200, B, L, scale=0.1)
+        est, pred = m(x, train=True)
+        loss = R_nl.ete_train_se_loss(weights).final_ete_loss(pred, m.stft(clean_ref), clean_ref, est)
+        loss[0].backward()
+    out = dict(x=x.detach(), clean_ref=clean_ref, seed=seed, base=base, weights=np.asarray(weights, dtype="float32"),
+               loss=torch.stack([v.detach() for v in loss]), gx=x.grad, est=est.detach())
+    grad_record(out, "", m)
+    with torch.no_grad():
+        adam_record(out, "", m)
+    save(f"grad_dccrn_{tag}", **out)
+
+
+def gen_grad_vae(tag, base, zdim, B, L, ns, seed):
+    print(f"== grads VAE {tag}: base={base} zdim={zdim} B={B} L={L} ns={ns}")
+    np_ = O.net_params(True, base)
+    skip = [0, 1, 2, 3, 4, 5]
+    T = 1 + L // HOP
+    orig = torch.randn_like
+    # ---- CVAE pre-training step (pretrained_vaes/train.py:281-301), recon weights incl. SI-SNR
+    w = [1.0, 1.0, 0.3]
+    with torch.enable_grad():
+        enc = R_pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cpu", zdim, NFFT, HOP, WIN, ns)
+        dec = R_pm.pvae_dccrn_decoder_skip_prepare(np_, True, "cpu", ns, zdim, NFFT, HOP, WIN, "real_imag", skip)
+        load_synth(enc, seed), load_synth(dec, seed + 1)
+        enc.train(), dec.train()
+        fix_bn_flags(enc, True), fix_bn_flags(dec, True)
+        x = rnd(seed + 100, B, L, scale=0.1)
+        eps = [rnd(seed + 300, B, ns, T, zdim), rnd(seed + 301, B, ns, T, zdim)]
+        draws = list(eps)
+        torch.randn_like = lambda t, *a, **k: draws.pop(0)
+        try:
+            z, miu, ls, dl, skiper, C, F, stft_x = enc(x, train=True)
+        finally:
+            torch.randn_like = orig
+        recon, pred = dec(stft_x, z, skiper, C, F, train=True)
+        xr = x.unsqueeze(1).repeat(1, ns, 1).view(B * ns, L)
+        sx = stft_x.unsqueeze(1).repeat(1, ns, 1, 1, 1).view(B * ns, stft_x.shape[1], stft_x.shape[2], 2)
+        pl = R_pl.complex_standard_vae_loss(torch.ones(1), 1.0, 0.0, 'multiple', 'real_imag', w, ns)
+        lo = pl.cal_loss(xr, recon, sx, pred, miu, ls, dl, z, 5)
+        lo[0].backward()
+    out = dict(x=x, eps_r=eps[0], eps_i=eps[1], seed=seed, base=base, zdim=zdim, ns=ns, weights=np.asarray(w, dtype="float32"),
+               loss=torch.stack([torch.as_tensor(v).detach().float() for v in (lo[0], lo[1], lo[2], lo[4], lo[5], lo[6])]))
+    grad_record(out, "enc.", enc)
+    grad_record(out, "dec.", dec)
+    with torch.no_grad():
+        adam_record(out, "enc.", enc), adam_record(out, "dec.", dec)
+    save(f"grad_cvae_{tag}", **out)
+
+    # ---- NSVAE step (train_nsvae.py:487-574): frozen clean / noise encoders (eval, no_grad), noisy encoder trains
+    with torch.enable_grad():
+        ce = R_pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cpu", zdim, NFFT, HOP, WIN, ns)
+        ne = R_pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cpu", zdim, NFFT, HOP, WIN, ns)
+        ye = R_pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cpu", zdim, NFFT, HOP, WIN, ns, 2)
+        load_synth(ce, seed + 4), load_synth(ne, seed + 5), load_synth(ye, seed + 6)
+        ye.train()
+        fix_bn_flags(ye, True)
+        clean = rnd(seed + 110, B, L, scale=0.1)
+        noise = rnd(seed + 111, B, L, scale=0.1)
+        noisy = clean + noise
+        epsn = [rnd(seed + 320 + i, B, ns, T, zdim) for i in range(8)]
+        draws = list(epsn)
+        torch.randn_like = lambda t, *a, **k: draws.pop(0)
+        try:
+            with torch.no_grad():
+                zc, mc, lc, dc, skc, _, _, _ = ce(clean, train=False)
+                zn, mn, ln_, dn, skn, _, _, _ = ne(noise, train=False)
+            r = ye(noisy, train=True)
+        finally:
+            torch.randn_like = orig
+        zs, ms, ls_, ds, znn, mnn, lnn, dnn, sky, C, F, stft_y = r
+        nl = R_nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.5, zdim, ns, 2, 'original', 'False', [], 'both')
+        ln_out = nl.final_nsvae_loss(mc, mn, ms, mnn, lc, ln_, ls_, lnn, dc, dn, ds, dnn, zs, znn, skc, skn, sky)
+        ln_out[0].backward()
+    out = dict(clean=clean, noise=noise, seed=seed, base=base, zdim=zdim, ns=ns,
+               **{f"eps{i}": e for i, e in enumerate(epsn)},
+               loss=torch.stack([torch.as_tensor(v).detach().float() for v in ln_out[:6]]))
+    grad_record(out, "noisy.", ye)
+    with torch.no_grad():
+        adam_record(out, "noisy.", ye)
+    save(f"grad_nsvae_{tag}", **out)
+
+    # ---- decoder fine-tune step (train_second_phase_decoder.py:376-433): frozen noisy encoder (eval), decoder trains
+    with torch.enable_grad():
+        ye2 = R_pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cpu", zdim, NFFT, HOP, WIN, ns, 2)
+        de2 = R_pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, "cpu", ns, zdim, NFFT, HOP, WIN, "mask", True, skip, False)
+        load_synth(ye2, seed + 6), load_synth(de2, seed + 7)
+        for p_ in ye2.parameters():
+            p_.requires_grad = False
+        de2.train()
+        fix_bn_flags(de2, True)
+        eps2 = [rnd(seed + 340 + i, B, ns, T, zdim) for i in range(4)]
+        draws = list(eps2)
+        torch.randn_like = lambda t, *a, **k: draws.pop(0)
+        try:
+            r = ye2(noisy, train=False)
+        finally:
+            torch.randn_like = orig
+        zs, _, _, _, _, _, _, _, sky, C, F, stft_y = r
+        rec, prd = de2(stft_y, zs, sky, C, F, train=True, pad='sig')
+        sxc = ye2.stft(clean).unsqueeze(1).repeat(1, ns, 1, 1, 1).view(B * ns, stft_y.shape[1], stft_y.shape[2], 2)
+        cb = clean.unsqueeze(1).repeat(1, ns, 1).view(B * ns, L)
+        tl = R_nl.two_phase_loss([0, 0, 1], 1.0, zdim, 1)
+        l2 = tl.phase_2_loss(prd, sxc, cb, rec, None, None, None, None)
+        l2[0].backward()
+    out = dict(clean=clean, noise=noise, seed=seed, base=base, zdim=zdim, ns=ns,
+               **{f"eps{i}": e for i, e in enumerate(eps2)},
+               loss=torch.stack([torch.as_tensor(v).detach().float() for v in l2[:4]]), recon=rec.detach())
+    grad_record(out, "dec.", de2)
+    with torch.no_grad():
+        adam_record(out, "dec.", de2)
+    save(f"grad_twophase_{tag}", **out)
+
+
+def sub(t, *steps):
+    idx = tuple(slice(None, None, s) for s in steps)
+    return t[idx].clone()
+
+
+def gen_vae_full(tag, B, ns, seed):
+    """Full-width VAE workloads (base 32, zdim 128 -> LSTM hidden 384 / 768) in eval mode, 4 s utterances; outputs stored
+    subsampled (+ norms) to keep the fixture small."""
+    base, zdim, L = 32, 128, 64000
+    print(f"== VAE full {tag}: B={B} ns={ns}")
+    np_ = O.net_params(True, base)
+    skip = [0, 1, 2, 3, 4, 5]
+    T = 1 + L // HOP
+    x = rnd(seed + 100, B, L, scale=0.1)
+    orig = torch.randn_like
+    enc = R_pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cpu", zdim, NFFT, HOP, WIN, ns)
+    dec = R_pm.pvae_dccrn_decoder_skip_prepare(np_, True, "cpu", ns, zdim, NFFT, HOP, WIN, "real_imag", skip)
+    load_synth(enc, seed), load_synth(dec, seed + 1)
+    eps = [rnd(seed + 300, B, ns, T, zdim), rnd(seed + 301, B, ns, T, zdim)]
+    draws = list(eps)
+    torch.randn_like = lambda t, *a, **k: draws.pop(0)
+    try:
+        z, miu, ls, dl, skiper, C, F, stft_x = enc(x, train=False)
+    finally:
+        torch.randn_like = orig
+    recon, pred = dec(stft_x, z, skiper, C, F, train=False)
+    xr = x.repeat_interleave(ns, dim=0)
+    sx = stft_x.repeat_interleave(ns, dim=0)
+    pl = R_pl.complex_standard_vae_loss(torch.ones(1), 1.0, 0.0, 'multiple', 'real_imag', [1.0, 1.0, 0.0], ns)
+    lo = pl.cal_loss(xr, recon, sx, pred, miu, ls, dl, z, 5)
+    save(f"vae_cvae_{tag}", x=x, seed=seed, base=base, zdim=zdim, ns=ns, train=0,
+         z_sub=sub(z, 1, 8, 4, 1), z_l2=z.double().norm(), miu_sub=sub(miu, 1, 8, 4, 1), miu_l2=miu.double().norm(),
+         ls_sub=sub(ls, 1, 8, 4, 1), dl_sub=sub(dl, 1, 8, 4, 1), skip5_sub=sub(skiper[5], 1, 8, 1, 8, 1),
+         recon_sub=sub(recon, 1, 16), recon_l2=recon.double().norm(),
+         pred_sub=sub(torch.view_as_real(pred), 1, 8, 16, 1), pred_l2=torch.view_as_real(pred).double().norm(),
+         elbo=torch.stack([torch.as_tensor(v).float() for v in (lo[0], lo[1], lo[2], lo[4], lo[5], lo[6])]))
+
+    enc2 = R_pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cpu", zdim, NFFT, HOP, WIN, ns, 2)
+    dec2 = R_pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, "cpu", ns, zdim, NFFT, HOP, WIN, "mask", True, skip, False)
+    load_synth(enc2, seed + 2), load_synth(dec2, seed + 3)
+    eps2 = [rnd(seed + 310 + i, B, ns, T, zdim) for i in range(4)]
+    draws = list(eps2)
+    torch.randn_like = lambda t, *a, **k: draws.pop(0)
+    try:
+        r = enc2(x, train=False)
+    finally:
+        torch.randn_like = orig
+    z_s, miu_s, ls_s, dl_s, z_n, miu_n, ls_n, dl_n, skiper2, C, F, stft_x2 = r
+    recon2, pred2 = dec2(stft_x2, z_s, skiper2, C, F, train=False, pad='sig')
+    tl = R_nl.two_phase_loss([0, 0, 1], 1.0, zdim, 1)
+    l2 = tl.phase_2_loss(pred2, sx, xr, recon2, None, None, None, None)
+    # nsvae loss of the noisy-encoder posteriors against the CVAE posterior above (clean = noise encoder here: data only)
+    nl = R_nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.0, zdim, ns, 2, 'original', 'False', [], 'both')
+    ln_out = nl.final_nsvae_loss(miu, miu, miu_s, miu_n, ls, ls, ls_s, ls_n, dl, dl, dl_s, dl_n, z_s, z_n, None, None, None)
+    save(f"vae_nsvae_{tag}", x=x, seed=seed, base=base, zdim=zdim, ns=ns, train=0,
+         z_speech_sub=sub(z_s, 1, 8, 4, 1), z_speech_l2=z_s.double().norm(), z_noise_sub=sub(z_n, 1, 8, 4, 1),
+         miu_speech_sub=sub(miu_s, 1, 8, 4, 1), miu_noise_sub=sub(miu_n, 1, 8, 4, 1), miu_noise_l2=miu_n.double().norm(),
+         ls_speech_sub=sub(ls_s, 1, 8, 4, 1), dl_noise_sub=sub(dl_n, 1, 8, 4, 1),
+         recon_sub=sub(recon2, 1, 16), recon_l2=recon2.double().norm(),
+         pred_sub=sub(torch.view_as_real(pred2), 1, 8, 16, 1),
+         phase2=torch.stack([torch.as_tensor(v).float() for v in l2[:4]]),
+         nsvae=torch.stack([torch.as_tensor(v).float() for v in ln_out[:4]]))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "mini", "full"]
     if "ops" in which:
@@ -346,3 +564,9 @@ if __name__ == "__main__":
     if "full" in which:
         torch.set_num_threads(os.cpu_count())
         gen_dccrn("full_eval", 32, 2, 64000, 51, train=False, full_outputs=False)
+    if "grads" in which:
+        gen_grad_dccrn("mini", 4, 2, 1600, 61, [0.2, 0.1, 1.0])
+        gen_grad_vae("mini", 4, 32, 2, 1600, 2, 71)
+    if "vaefull" in which:
+        torch.set_num_threads(os.cpu_count())
+        gen_vae_full("full_eval", 1, 2, 81)
