@@ -23,6 +23,8 @@ struct RecArgs {
     const float* whh;     // [2 sets][4H/16 tiles][H/4][64]
     float* hout;          // [4 runs][T*B][H]
     int H, B, T;
+    float* gsave;         // training: activated gates (i, f, g, o) written back over the pre-activations (same addressing as g)
+    float* csave;         // training: cell state per step, [4 runs][T*B][H]
 };
 
 template <bool WREG>
@@ -40,6 +42,8 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(const RecArgs a) {
     const float* g = a.g + z * a.g_run_z + s * a.g_run_s;
     const float* whh = a.whh + (size_t)s * 4 * H * H;
     float* hout = a.hout + (size_t)run * a.T * a.B * H;
+    float* gsv = a.gsave ? a.gsave + z * a.g_run_z + s * a.g_run_s : nullptr;
+    float* csv = a.csave ? a.csave + (size_t)run * a.T * a.B * H : nullptr;
 
     for (int e = tid; e < 2 * H * 16 + (WREG ? 0 : H * 16); e += 256) sm[e] = 0.f;
 
@@ -109,7 +113,14 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(const RecArgs a) {
                     creg[u][r] = cn;
                     hv[r] = og * tanhf_(cn);
                     const int row = rq * 4 + r;
-                    if (b0 + row < a.B) hout[(rowbase + row) * H + unit] = hv[r];
+                    if (b0 + row < a.B) {
+                        hout[(rowbase + row) * H + unit] = hv[r];
+                        if (gsv) {
+                            float* gp = gsv + (rowbase + row) * a.ldg + ((wave + 4 * u) * 4) * 16 + col;
+                            gp[0] = ig; gp[16] = fg; gp[32] = gv; gp[48] = og;
+                            csv[(rowbase + row) * H + unit] = cn;
+                        }
+                    }
                 }
                 *(f32x4*)&hn[unit * 16 + rq * 4] = hv;
             }
@@ -146,7 +157,14 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(const RecArgs a) {
                     cv[r] = cn;
                     hv[r] = og * tanhf_(cn);
                     const int row = rq * 4 + r;
-                    if (b0 + row < a.B) hout[(rowbase + row) * H + unit] = hv[r];
+                    if (b0 + row < a.B) {
+                        hout[(rowbase + row) * H + unit] = hv[r];
+                        if (gsv) {
+                            float* gp = gsv + (rowbase + row) * a.ldg + (ub * 4) * 16 + col;
+                            gp[0] = ig; gp[16] = fg; gp[32] = gv; gp[48] = og;
+                            csv[(rowbase + row) * H + unit] = cn;
+                        }
+                    }
                 }
                 *(f32x4*)&cS[unit * 16 + rq * 4] = cv;
                 *(f32x4*)&hn[unit * 16 + rq * 4] = hv;
@@ -367,6 +385,11 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs sa) {
             const float cn = fg * cpre[r] + ig * gv;
             cst[ci] = cn;
             hout[(rowbase + row) * H + unit] = og * tanhf_(cn);
+            if (a.gsave) {
+                float* gp = a.gsave + z * a.g_run_z + s * a.g_run_s + (rowbase + row) * a.ldg + ub * 64 + col;
+                gp[0] = ig; gp[16] = fg; gp[32] = gv; gp[48] = og;
+                a.csave[(size_t)run * a.T * a.B * H + (rowbase + row) * H + unit] = cn;
+            }
         }
     }
 }
@@ -565,6 +588,11 @@ int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
 extern "C" long long idv_clstm_work_floats(int H, int B, int T, int Jp) {
     return 24LL * T * B * H + 4LL * B * H + 4LL * H * Jp;
 }
+// training (flags bit 2): both layers' gate buffers and the cell states are kept for the backward pass
+//   [G0 16TBH | G1 16TBH | h0 4TBH | h1 4TBH | c0 4TBH | c1 4TBH | cstate 4BH | hp 4*H*Jp]
+extern "C" long long idv_clstm_train_work_floats(int H, int B, int T, int Jp) {
+    return 48LL * T * B * H + 4LL * B * H + 4LL * H * Jp;
+}
 
 extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
                              const float* wih1, const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp,
@@ -574,10 +602,15 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     if ((size_t)3 * H * 16 * sizeof(float) > 160 * 1024) return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const long long TB = (long long)T * B;
-    float* G = work;                       // [2][TB][8H]  then  [4][TB][4H]
-    float* h0 = work + 16 * TB * H;        // [4][TB][H]
+    const bool save = (flags & 4) != 0;
+    if (save && (flags & 1)) return IDV_EINVAL;         // the training forward keeps the exact-fp32 recurrence
+    float* G = work;                       // [2][TB][8H]  then (inference: same memory)  [4][TB][4H]
+    float* G1 = save ? work + 16 * TB * H : work;
+    float* h0 = (save ? G1 : work) + 16 * TB * H;        // [4][TB][H]
     float* h1 = h0 + 4 * TB * H;
-    float* cstate = h1 + 4 * TB * H;       // [4][B][H], used by the per-step kernel only
+    float* c0 = save ? h1 + 4 * TB * H : nullptr;
+    float* c1 = save ? c0 + 4 * TB * H : nullptr;
+    float* cstate = (save ? c1 : h1) + 4 * TB * H;       // [4][B][H], used by the per-step kernel only
     int rc;
     // layer 0 input projection: both weight sets at once (M = 8H), one call per input part z
     // (flags bit 1: the caller already filled G through idv_lstm_proj_bf16x3)
@@ -586,13 +619,13 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
                          8 * H, stream);
         if (rc) return rc;
     }
-    RecArgs r0{G, TB * 8 * H, 4LL * H, 8 * H, whh0, h0, H, B, T};
+    RecArgs r0{G, TB * 8 * H, 4LL * H, 8 * H, whh0, h0, H, B, T, save ? G : nullptr, c0};
     if ((rc = launch_rec(r0, cstate, flags, st))) return rc;
     // layer 1 input projection from h0 (row-major), per run
     const int KS = ((H + 7) / 8) * 4;
     dim3 ggrid((unsigned)((TB + 31) / 32), 4);
     if (H == 128) {
-        hipLaunchKernelGGL(gemm_rm_kernel<4>, ggrid, dim3(256), 0, st, h0, wih1, bih1, G, H, TB, KS);
+        hipLaunchKernelGGL(gemm_rm_kernel<4>, ggrid, dim3(256), 0, st, h0, wih1, bih1, G1, H, TB, KS);
     } else if (H % 32 == 0) {
         // transpose h0 to planar and use the PW contraction: rows of weight set s start at tile s*(4H/32)
         float* hp = cstate + 4LL * B * H;              // [4 runs][H][Jp]
@@ -601,7 +634,7 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
         for (int run = 0; run < 4; ++run) {
             const int sset = run & 1;
             rc = idv_pw_gemm(hp + (size_t)run * H * Jp, H, wih1 + (size_t)sset * (4 * H / 32) * KS * 64, bih1 + sset * 4 * H, nullptr,
-                             G + (size_t)run * TB * 4 * H, 4 * H, B, Tp, Jp, T, 1, 4 * H, stream);
+                             G1 + (size_t)run * TB * 4 * H, 4 * H, B, Tp, Jp, T, 1, 4 * H, stream);
             if (rc) return rc;
         }
     } else {
@@ -609,11 +642,11 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
         if (smem > 64 * 1024 &&
             hipFuncSetAttribute((const void*)gemm_rm_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return IDV_ELAUNCH;
-        hipLaunchKernelGGL(gemm_rm_generic_kernel, ggrid, dim3(256), smem, st, h0, wih1, bih1, G, H, TB, KS);
+        hipLaunchKernelGGL(gemm_rm_generic_kernel, ggrid, dim3(256), smem, st, h0, wih1, bih1, G1, H, TB, KS);
     }
     if ((rc = idv_launch_status())) return rc;
     // G1 is [run][TB][4H] with run = 2z + s
-    RecArgs r1{G, 2 * TB * 4 * H, TB * 4 * H, 4 * H, whh1, h1, H, B, T};
+    RecArgs r1{G1, 2 * TB * 4 * H, TB * 4 * H, 4 * H, whh1, h1, H, B, T, save ? G1 : nullptr, c1};
     if ((rc = launch_rec(r1, cstate, flags, st))) return rc;
     hipLaunchKernelGGL(lstm_combine_kernel, dim3((T + 31) / 32, (H + 31) / 32, B), dim3(256), 0, st, h1, H, B, T, Tp, Jp, out);
     const long long ntail = 2LL * H * B * (Tp - 1 - T);

@@ -9,7 +9,7 @@ namespace {
 __global__ void pack_cconv_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im,
                                   const float* __restrict__ b_re, const float* __restrict__ b_im,
                                   const float* __restrict__ fold, int Cout, int Cin_total, int Cin_used, int transposed,
-                                  int KS, int Mtiles, float* __restrict__ wfrag, float* __restrict__ bias_out) {
+                                  int KS, int Mtiles, float* __restrict__ wfrag, float* __restrict__ bias_out, int conj) {
     const long long n = (long long)Mtiles * KS * 64;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
@@ -25,7 +25,7 @@ __global__ void pack_cconv_kernel(const float* __restrict__ w_re, const float* _
             const int kt = transposed ? 1 - h : h;
             const size_t off = transposed ? (((size_t)ci * Cout + co) * 5 + kf) * 2 + kt
                                           : (((size_t)co * Cin_total + ci) * 5 + kf) * 2 + kt;
-            const float wr = w_re[off], wi = w_im[off];
+            const float wr = w_re[off], wi = conj ? -w_im[off] : w_im[off];
             // rows of [[Wr, -Wi], [Wi, Wr]] for this input plane
             const float top = ri == 0 ? wr : -wi;   // contributes to the real output
             const float bot = ri == 0 ? wi : wr;    // contributes to the imag output
@@ -42,7 +42,7 @@ __global__ void pack_cconv_kernel(const float* __restrict__ w_re, const float* _
     for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < nb; m += gridDim.x * blockDim.x) {
         const int co = m >> 1, ro = m & 1;
         float v = 0.f;
-        if (co < Cout) {
+        if (co < Cout && b_re) {
             const float top = b_re[co] - b_im[co], bot = b_re[co] + b_im[co];
             if (fold) {
                 const float* z = fold + (size_t)co * 6;
@@ -238,7 +238,23 @@ extern "C" int idv_pack_cconv(const float* w_re, const float* w_im, const float*
     const int KS = CCp * 5;
     const int Mtiles = ((2 * Cout + 127) / 128) * 4;
     hipLaunchKernelGGL(pack_cconv_kernel, dim3(grid_for((long long)Mtiles * KS * 64)), dim3(256), 0, (hipStream_t)stream,
-                       w_re, w_im, b_re, b_im, fold, Cout, Cin_total, Cin_used, transposed, KS, Mtiles, wfrag, bias_out);
+                       w_re, w_im, b_re, b_im, fold, Cout, Cin_total, Cin_used, transposed, KS, Mtiles, wfrag, bias_out, 0);
+    return idv_launch_status();
+}
+
+// Weights of the ADJOINT operator (data gradient): the same parameter tensor read with the other layout
+// (conv weights [Cout][Cin] as transposed-conv weights [Cin' = Cout][Cout' = Cin] and vice versa), imaginary part
+// negated, no bias.  `transposed` is the mode of the adjoint operator itself.
+extern "C" int idv_pack_cconv_adjoint(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used,
+                                      int transposed, float* wfrag, float* bias_out, void* stream) {
+    if (!w_re || !w_im || !wfrag || !bias_out || Cout <= 0 || Cin_used <= 0 || Cin_used > Cin_total) return IDV_EINVAL;
+    const int cck = idv_cconv_cck(Cin_used);
+    const int CCp = ((2 * Cin_used + cck - 1) / cck) * cck;
+    const int KS = CCp * 5;
+    const int Mtiles = ((2 * Cout + 127) / 128) * 4;
+    hipLaunchKernelGGL(pack_cconv_kernel, dim3(grid_for((long long)Mtiles * KS * 64)), dim3(256), 0, (hipStream_t)stream,
+                       w_re, w_im, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Cout, Cin_total, Cin_used,
+                       transposed, KS, Mtiles, wfrag, bias_out, 1);
     return idv_launch_status();
 }
 

@@ -1,0 +1,351 @@
+// Weight gradients of the complex conv / transposed conv / point-wise contractions (backward row):
+// what torch.autograd computes behind `loss.backward()` in the reference's train steps
+// (supervised_dccrn/train.py:239-243, pretrained_vaes/train.py:296-301, train_nsvae.py:557-561,
+// train_second_phase_decoder.py:420-433) for nn.Conv2d / nn.ConvTranspose2d (model/complex_progress.py:8-36, :222-279),
+// nn.Linear (:77-89) and the nn.LSTM input projections (:39-74).
+//
+// One contraction for all of them.  With S the "small" planar tensor (rows fs) and L the "large" one
+// (rows fl = 2*fs + kf - 2; conv: S = dy, L = x; transposed conv: S = x, L = dy):
+//
+//   G[kf][kt][sp][lp] = sum_{fs, j} S[sp][fs][j] * L[lp][2*fs + kf - 2][j + kt + dt0]
+//
+// i.e. a GEMM with M = S planes, N = L planes x 10 taps and K = Fs x J (millions) -> split-K: every workgroup
+// owns one (128 S planes x 64 L planes x 10 taps) output tile over a contiguous range of column tiles and
+// writes its partial tile to a workspace; the unpack kernel sums the partials in a fixed order (deterministic,
+// no atomics) and folds the four real products of a complex pair into (dW_re, dW_im).
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32).  As in the forward kernel the two k of one instruction are two
+// adjacent columns: lanes 0-31 read LDS column c, lanes 32-63 column c+1, so the time tap is a free column
+// offset and all LDS reads are conflict free (row pitch 34 words, plane pitch 170 words).
+#include "common.hpp"
+#include "../../include/idccrn_hip.h"
+
+namespace {
+
+struct WgradArgs {
+    const float* S;      // planar [Sp][Fs][JpS]
+    const float* L;      // planar [Lp][Fl][JpL]
+    int Sp, Lp, Fs, Fl;
+    int J, JpS, JpL;
+    int dt0;             // L column = S column + kt + dt0
+    float* part;         // [nsplit][TAPS][SpPad][LpPad]
+    int SpPad, LpPad;
+    int jtiles;          // ceil(J / WG_JT)
+    int jt_per_split;
+};
+
+// WG_JT columns per step; LDS row pitch WG_JT + 2 words (pitch/2 odd -> 64 distinct banks for (plane, half))
+// KF x KT taps; MT_W / NT_W 32-plane tiles per wave along S / L; 2 x 2 waves
+template <int KF, int KT, int MT_W, int NT_W, int WG_JT>
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
+    constexpr int WG_PS = WG_JT + 2;
+    constexpr int Q4 = WG_JT / 4;                             // float4 slots per row
+    constexpr int KUNR = (KF * KT > 1) ? 1 : 4;               // 20 accumulator tiles leave no room to unroll the k loop
+    static_assert(((WG_PS / 2) & 1) == 1 && ((KF * WG_PS / 2) & 1) == 1, "LDS pitches must be 2 * odd");
+    constexpr int MS = 2 * MT_W * 32, ML = 2 * NT_W * 32;
+    constexpr int TAPS = KF * KT;
+    constexpr int S_SLOTS = MS * (WG_JT / 4);                 // float4 slots of the S tile
+    constexpr int L_ROWS = ML * KF;
+    constexpr int L_SLOTS = L_ROWS * (WG_JT / 4);
+    constexpr int NS4 = (S_SLOTS + 255) / 256, NL4 = (L_SLOTS + 255) / 256;
+    constexpr int NH = (L_ROWS * 2 + 255) / 256;              // halo elements (columns j0-1 and j0+32) per thread
+    __shared__ float Ssm[MS * WG_PS];
+    __shared__ float Lsm[L_ROWS * WG_PS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int split = blockIdx.x, ts = blockIdx.y, tl = blockIdx.z;
+    const int sp0 = ts * MS, lp0 = tl * ML;
+    const int jt0 = split * a.jt_per_split;
+    int jt1 = jt0 + a.jt_per_split;
+    if (jt1 > a.jtiles) jt1 = a.jtiles;
+    const int nsteps = (jt1 > jt0) ? (jt1 - jt0) * a.Fs : 0;
+
+    f32x16 acc[MT_W][NT_W][TAPS];
+#pragma unroll
+    for (int i = 0; i < MT_W; ++i)
+#pragma unroll
+        for (int n = 0; n < NT_W; ++n)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][n][t][r] = 0.f;
+
+    f32x4 sreg[NS4], lreg[NL4];
+    float hreg[NH];
+
+    auto load_step = [&](int step) {
+        const int jt = jt0 + step / a.Fs, fs = step - (step / a.Fs) * a.Fs;
+        const int j0 = jt * WG_JT;
+#pragma unroll
+        for (int i = 0; i < NS4; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int sp = sp0 + row, j = j0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < S_SLOTS && sp < a.Sp && j < a.J) {
+                v = *(const f32x4*)(a.S + ((size_t)sp * a.Fs + fs) * a.JpS + j);
+#pragma unroll
+                for (int c = 1; c < 4; ++c)
+                    if (j + c >= a.J) v[c] = 0.f;
+            }
+            sreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NL4; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int pl = row / KF, kf = row - pl * KF;
+            const int lp = lp0 + pl, fl = (KF == 1) ? fs : 2 * fs + kf - 2, j = j0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < L_SLOTS && lp < a.Lp && fl >= 0 && fl < a.Fl && j < a.J) {
+                v = *(const f32x4*)(a.L + ((size_t)lp * a.Fl + fl) * a.JpL + j);
+#pragma unroll
+                for (int c = 1; c < 4; ++c)
+                    if (j + c >= a.J) v[c] = 0.f;
+            }
+            lreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int e = tid + i * 256;
+            const int row = e >> 1, side = e & 1;
+            const int pl = row / KF, kf = row - pl * KF;
+            const int lp = lp0 + pl, fl = (KF == 1) ? fs : 2 * fs + kf - 2;
+            const int j = side ? j0 + WG_JT : j0 - 1;
+            float v = 0.f;
+            if (e < L_ROWS * 2 && lp < a.Lp && fl >= 0 && fl < a.Fl && j >= 0 && j < a.J)
+                v = a.L[((size_t)lp * a.Fl + fl) * a.JpL + j];
+            hreg[i] = v;
+        }
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < NS4; ++i) {
+            const int e = tid + i * 256;
+            if (e < S_SLOTS) {
+                float* d = Ssm + (e / Q4) * WG_PS + 4 * (e % Q4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[c] = sreg[i][c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NL4; ++i) {
+            const int e = tid + i * 256;
+            if (e < L_SLOTS) {
+                float* d = Lsm + (e / Q4) * WG_PS + 1 + 4 * (e % Q4);      // LDS column c = j - j0 + 1
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[c] = lreg[i][c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int e = tid + i * 256;
+            if (e < L_ROWS * 2) Lsm[(e >> 1) * WG_PS + ((e & 1) ? WG_JT + 1 : 0)] = hreg[i];
+        }
+    };
+
+    if (nsteps > 0) load_step(0);
+    for (int step = 0; step < nsteps; ++step) {
+        store_step();
+        __syncthreads();
+        if (step + 1 < nsteps) load_step(step + 1);      // global loads fly under this step's MFMAs
+        const float* As = Ssm + (wm * MT_W * 32 + l31) * WG_PS + half;
+        const float* Bs = Lsm + ((wn * NT_W * 32 + l31) * KF) * WG_PS + half + 1 + a.dt0;
+#pragma unroll KUNR
+        for (int ks = 0; ks < WG_JT / 2; ++ks) {
+            const int col = 2 * ks;
+            float av[MT_W];
+#pragma unroll
+            for (int i = 0; i < MT_W; ++i) av[i] = As[i * 32 * WG_PS + col];
+#pragma unroll
+            for (int n = 0; n < NT_W; ++n)
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        const float bv = Bs[(n * 32 * KF + kf) * WG_PS + col + kt];
+#pragma unroll
+                        for (int i = 0; i < MT_W; ++i)
+                            acc[i][n][kf * KT + kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][n][kf * KT + kt], 0, 0, 0);
+                    }
+        }
+        __syncthreads();
+    }
+
+    // partial tile -> workspace (every slot of the padded tile is written, so the workspace needs no clearing)
+    float* P = a.part + (size_t)split * TAPS * a.SpPad * a.LpPad;
+#pragma unroll
+    for (int i = 0; i < MT_W; ++i)
+#pragma unroll
+        for (int n = 0; n < NT_W; ++n)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sp = sp0 + (wm * MT_W + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int lp = lp0 + (wn * NT_W + n) * 32 + l31;
+                    P[((size_t)t * a.SpPad + sp) * a.LpPad + lp] = acc[i][n][t][r];
+                }
+}
+
+// (dW_re, dW_im)[.., kf, kt] from the partial real-block gradients; one thread per complex weight element.
+// conv (transposed = 0): S = dy planes (ro*Cout + co), L = x planes (ri*Cx + cil); weight [Cout][Cin_total][5][2]
+// tconv (transposed = 1): S = x planes (ri*Cx + cil), L = dy planes (ro*Cout + co); weight [Cin_total][Cout][5][2]
+__global__ void wgrad_unpack_conv_kernel(const float* __restrict__ part, int nsplit, int SpPad, int LpPad, int Cout, int Cx,
+                                         int Cin_total, int ci_off, int transposed, float* __restrict__ dw_re,
+                                         float* __restrict__ dw_im) {
+    const long long n = (long long)Cout * Cx * 10;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(idx % 10);
+        const int cil = (int)((idx / 10) % Cx);
+        const int co = (int)(idx / (10LL * Cx));
+        int s_re, s_im, l_re, l_im;
+        if (!transposed) { s_re = co; s_im = Cout + co; l_re = cil; l_im = Cx + cil; }
+        else             { s_re = cil; s_im = Cx + cil; l_re = co; l_im = Cout + co; }
+        double rr = 0, ii = 0, ri = 0, ir = 0;      // G[s_re][l_re], G[s_im][l_im], G[s_re][l_im], G[s_im][l_re]
+        const size_t plane = (size_t)SpPad * LpPad;
+        for (int sidx = 0; sidx < nsplit; ++sidx) {
+            const float* P = part + ((size_t)sidx * 10 + tap) * plane;
+            rr += P[(size_t)s_re * LpPad + l_re];
+            ii += P[(size_t)s_im * LpPad + l_im];
+            ri += P[(size_t)s_re * LpPad + l_im];
+            ir += P[(size_t)s_im * LpPad + l_re];
+        }
+        // y_r = Wr x_r - Wi x_i, y_i = Wi x_r + Wr x_i  ->  dWr = dy_r x_r + dy_i x_i,  dWi = -dy_r x_i + dy_i x_r
+        const double dwr = rr + ii;
+        const double dwi = transposed ? (ri - ir) : (ir - ri);
+        const int ci = ci_off + cil;
+        const size_t o = transposed ? (((size_t)ci * Cout + co) * 10 + tap) : (((size_t)co * Cin_total + ci) * 10 + tap);
+        dw_re[o] = (float)dwr;
+        dw_im[o] = (float)dwi;
+    }
+}
+
+// out[rowmap(m)][k] (+)= sum_splits part[split][0][m][k];  rowmap: 0 identity, 1 LSTM gate order (colp -> g*H + u)
+__global__ void wgrad_unpack_plain_kernel(const float* __restrict__ part, int nsplit, int SpPad, int LpPad, int M, int K,
+                                          int ldo, int rowmap, int H, int accumulate, float* __restrict__ out) {
+    const long long n = (long long)M * K;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % K), m = (int)(idx / K);
+        double s = 0;
+        for (int sidx = 0; sidx < nsplit; ++sidx) s += part[((size_t)sidx * SpPad + m) * LpPad + k];
+        int row = m;
+        if (rowmap == 1) {
+            const int set = m / (4 * H), colp = m - set * 4 * H;
+            const int ub = colp >> 6, g = (colp >> 4) & 3, ul = colp & 15;
+            row = set * 4 * H + g * H + ub * 16 + ul;
+        }
+        float* d = out + (size_t)row * ldo + k;
+        *d = accumulate ? *d + (float)s : (float)s;
+    }
+}
+
+__global__ void cconv_bias_grad_kernel(const double* __restrict__ stats, int Cout, float* __restrict__ db_re,
+                                       float* __restrict__ db_im) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cout) return;
+    const double sr = stats[(size_t)c * 5], si = stats[(size_t)c * 5 + 1];
+    db_re[c] = (float)(sr + si);      // out_r carries b_re - b_im, out_i carries b_re + b_im (complex_progress.py:16-18)
+    db_im[c] = (float)(si - sr);
+}
+
+constexpr int CONV_JT = 16, PW_JT = 32;
+
+struct Plan { int tilesS, tilesL, nsplit, jtiles, jt_per_split, SpPad, LpPad; };
+
+inline Plan make_plan(int Sp, int Lp, int J, int MS, int ML, int JT) {
+    Plan p;
+    p.tilesS = (Sp + MS - 1) / MS;
+    p.tilesL = (Lp + ML - 1) / ML;
+    p.SpPad = p.tilesS * MS;
+    p.LpPad = p.tilesL * ML;
+    p.jtiles = (J + JT - 1) / JT;
+    int want = (1024 + p.tilesS * p.tilesL - 1) / (p.tilesS * p.tilesL);
+    if (want < 1) want = 1;
+    if (want > p.jtiles) want = p.jtiles;
+    p.jt_per_split = (p.jtiles + want - 1) / want;
+    p.nsplit = (p.jtiles + p.jt_per_split - 1) / p.jt_per_split;
+    return p;
+}
+
+inline int grid_for(long long n) {
+    long long g = (n + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" long long idv_cconv_wgrad_work_floats(int Cs, int Cl, int B, int Tp) {
+    if (Cs <= 0 || Cl <= 0 || B <= 0 || Tp <= 0) return -1;
+    const Plan p = make_plan(2 * Cs, 2 * Cl, B * Tp, 128, 64, CONV_JT);
+    return (long long)p.nsplit * 10 * p.SpPad * p.LpPad;
+}
+
+extern "C" int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const float* dy, int Cout, int Cin_total,
+                                      int transposed, int tshift, int Fin, int B, int Tp, int Jp_x, int Jp_dy, float* work,
+                                      long long work_floats, float* dw_re, float* dw_im, void* stream) {
+    if (!x || !dy || !work || !dw_re || !dw_im || Cx <= 0 || Cout <= 0 || ci_off < 0 || ci_off + Cx > Cin_total || Fin <= 0 ||
+        B <= 0 || Tp <= 1)
+        return IDV_EINVAL;
+    if ((tshift != 0 && tshift != -1) || (Jp_x % 4) || (Jp_dy % 4) || !aligned16(x) || !aligned16(dy) || Jp_x < B * Tp ||
+        Jp_dy < B * Tp)
+        return IDV_EINVAL;
+    const int Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
+    WgradArgs a{};
+    if (!transposed) {      // S = dy [2Cout][Fout], L = x [2Cx][Fin]
+        if (2 * Fout - 1 != Fin) return IDV_EINVAL;
+        a.S = dy; a.Sp = 2 * Cout; a.Fs = Fout; a.JpS = Jp_dy;
+        a.L = x;  a.Lp = 2 * Cx;   a.Fl = Fin;  a.JpL = Jp_x;
+        a.dt0 = tshift;
+    } else {                // S = x [2Cx][Fin], L = dy [2Cout][Fout]
+        a.S = x;  a.Sp = 2 * Cx;   a.Fs = Fin;  a.JpS = Jp_x;
+        a.L = dy; a.Lp = 2 * Cout; a.Fl = Fout; a.JpL = Jp_dy;
+        a.dt0 = 0;
+    }
+    a.J = B * Tp;
+    const Plan p = make_plan(a.Sp, a.Lp, a.J, 128, 64, CONV_JT);
+    if ((long long)p.nsplit * 10 * p.SpPad * p.LpPad > work_floats) return IDV_EINVAL;
+    a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles; a.jt_per_split = p.jt_per_split;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((wgrad_kernel<5, 2, 2, 1, CONV_JT>), dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_unpack_conv_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work, p.nsplit,
+                       p.SpPad, p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
+    return idv_launch_status();
+}
+
+extern "C" int idv_cconv2d_bwd_bias(const double* stats_dy, int Cout, float* db_re, float* db_im, void* stream) {
+    if (!stats_dy || !db_re || !db_im || Cout <= 0) return IDV_EINVAL;
+    hipLaunchKernelGGL(cconv_bias_grad_kernel, dim3((Cout + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats_dy, Cout, db_re,
+                       db_im);
+    return idv_launch_status();
+}
+
+extern "C" long long idv_pw_wgrad_work_floats(int M, int K, int J) {
+    if (M <= 0 || K <= 0 || J <= 0) return -1;
+    const Plan p = make_plan(M, K, J, 128, 128, PW_JT);
+    return (long long)p.nsplit * p.SpPad * p.LpPad;
+}
+
+extern "C" int idv_pw_bwd_weight(const float* dout, int M, int Jp_d, const float* x, int K, int Jp_x, int J, int shift,
+                                 float* work, long long work_floats, float* dw, int ldw, int rowmap, int H, int accumulate,
+                                 void* stream) {
+    if (!dout || !x || !work || !dw || M <= 0 || K <= 0 || J <= 0 || ldw < K || (shift != 0 && shift != -1)) return IDV_EINVAL;
+    if ((Jp_d % 4) || (Jp_x % 4) || !aligned16(dout) || !aligned16(x) || Jp_d < J || Jp_x < J) return IDV_EINVAL;
+    if (rowmap == 1 && (H <= 0 || (H % 16) || M % (4 * H))) return IDV_EINVAL;
+    WgradArgs a{};
+    a.S = dout; a.Sp = M; a.Fs = 1; a.JpS = Jp_d;
+    a.L = x;    a.Lp = K; a.Fl = 1; a.JpL = Jp_x;
+    a.dt0 = shift; a.J = J;
+    const Plan p = make_plan(M, K, J, 128, 128, PW_JT);
+    if ((long long)p.nsplit * p.SpPad * p.LpPad > work_floats) return IDV_EINVAL;
+    a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles; a.jt_per_split = p.jt_per_split;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((wgrad_kernel<1, 1, 2, 2, PW_JT>), dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_unpack_plain_kernel, dim3(grid_for((long long)M * K)), dim3(256), 0, st, work, p.nsplit, p.SpPad,
+                       p.LpPad, M, K, ldw, rowmap, H, accumulate, dw);
+    return idv_launch_status();
+}

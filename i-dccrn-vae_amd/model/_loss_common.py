@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import torch
 
+from .. import autograd as AG
 from .. import ops
 from ..ops import Planar
 from .sisnr_loss import si_snr
@@ -25,11 +26,12 @@ def latent_ref(miu, log_sigma, delta):
 def kl_mean(q1, q2, zdim: int, eps: float) -> torch.Tensor:
     """mean over (b, t) of KL(q1 || q2); q = (miu, log_sigma, delta); q2 None = prior (0, 0, 0)."""
     p1, o1 = latent_ref(*q1)
-    if q2 is None:
-        return ops.ckl(p1, o1, None, None, zdim, eps)
-    p2, o2 = latent_ref(*q2)
-    if (p1.B, p1.T, p1.Tp) != (p2.B, p2.T, p2.Tp):
+    p2, o2 = (None, None) if q2 is None else latent_ref(*q2)
+    if p2 is not None and (p1.B, p1.T, p1.Tp) != (p2.B, p2.T, p2.Tp):
         raise RuntimeError("KL operands must share batch and frame counts")
+    if AG.grad_mode(p1.buf, p2.buf if p2 is not None else None):
+        return AG.CklFn.apply(AG._geom(p1), tuple(o1), AG._geom(p2) if p2 is not None else None,
+                              tuple(o2) if o2 is not None else None, zdim, eps, p1.buf, p2.buf if p2 is not None else None)
     return ops.ckl(p1, o1, p2, o2, zdim, eps)
 
 
@@ -38,10 +40,14 @@ def recon_terms(predict_cpx_stft, ori_cpx_stft, source, est_source, weights):
     pc = predict_cpx_stft
     if not torch.view_as_real(pc).is_contiguous():
         pc = pc.contiguous()
+    ops.check_dev_f32(ori_cpx_stft, "ori_cpx_stft", pc.device)
     div = 1
     if ori_cpx_stft.shape[0] != pc.shape[0]:
         div = pc.shape[0] // ori_cpx_stft.shape[0]
-    loss_cpx, loss_mag = ops.recon_loss(pc, ori_cpx_stft.float(), div)
+    if AG.grad_mode(pc):
+        loss_cpx, loss_mag = AG.ReconLossFn.apply(torch.view_as_real(pc), ori_cpx_stft.detach().float(), div)
+    else:
+        loss_cpx, loss_mag = ops.recon_loss(pc, ori_cpx_stft.float(), div)
     sisnr = si_snr(source, est_source)
     final = weights[0] * loss_cpx + weights[1] * loss_mag + weights[2] * sisnr
     return final, loss_cpx, loss_mag, sisnr

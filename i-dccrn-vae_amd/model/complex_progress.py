@@ -10,7 +10,9 @@ never called.  Every layer has two faces:
 * ``forward_planar(...)`` on :class:`ops.Planar` activations, which the model classes chain so
   that an utterance batch stays in the planar-J device layout from STFT to ISTFT.
 
-Forward only (round 1): outputs carry no autograd graph.
+Training: with ``train=True`` under ``torch.enable_grad()`` the layers run through the ``torch.autograd.Function``
+classes of ``autograd.py`` (HIP backward kernels), so ``loss.backward()`` fills ``.grad`` of the parameters exactly as
+in the reference's train steps; eval-mode outputs carry no graph.
 """
 from __future__ import annotations
 
@@ -19,6 +21,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from .. import autograd as AG
 from .. import ops
 from ..ops import Planar
 
@@ -42,6 +45,16 @@ def tag5(pl: Planar) -> torch.Tensor:
     t = pl.tensor5()
     t._idv = pl
     return t
+
+
+def invalidate_caches(module: nn.Module):
+    """Drop every packed-weight / folded-BN cache below `module`.  The caches key on (data_ptr, _version), which covers
+    optimizer steps, load_state_dict and in-place edits of the parameters themselves; writes that bypass the version
+    counter (``p.data.copy_(...)``, raw-pointer kernels) need this call."""
+    for m in module.modules():
+        for v in vars(m).values():
+            if isinstance(v, _PackCache):
+                v.key = None
 
 
 class _PackCache:
@@ -259,7 +272,11 @@ class ComplexBatchNormal(nn.Module):
 
     def forward(self, x, train=True):
         src = planar_of(x)
-        act = Planar(src.buf.clone(), src.C, src.F, src.B, src.T, src.Tp, src.Jp)   # inputs are not mutated
+        if train and AG.grad_mode(src.buf, self.gamma_rr, self.gamma_ri, self.gamma_ii, self.beta_r, self.beta_i):
+            zbuf = AG.BatchNormFn.apply(self, AG._geom(src), src.buf, self.gamma_rr, self.gamma_ri, self.gamma_ii, self.beta_r,
+                                        self.beta_i)
+            return tag5(ops.rewrap(zbuf, src))
+        act = Planar(src.buf.detach().clone(), src.C, src.F, src.B, src.T, src.Tp, src.Jp)   # inputs are not mutated
         if train:
             self.finish_train(act, ops.cbn_stats(act))
         else:
@@ -300,6 +317,10 @@ class ComplexLSTM(nn.Module):
         """x: planar with C*F == input_size feature planes per part -> planar [2][H][Jp]."""
         if x.C * x.F != self.input_size:
             raise RuntimeError(f"ComplexLSTM expects {self.input_size} features, got {x.C}*{x.F}")
+        if AG.grad_mode(x.buf, *self.parameters()):
+            if not self._ok:
+                self._packed()
+            return AG.lstm(self, x)
         p0, p1 = self._packed()
         return ops.clstm(x, p0, p1, self.hidden_size)
 
@@ -332,6 +353,10 @@ class ComplexDense(nn.Module):
     def forward_planar(self, x: Planar, C_out: int, F_out: int) -> Planar:
         if x.C * x.F != self.in_channel or C_out * F_out != self.out_channel:
             raise RuntimeError("ComplexDense shape mismatch")
+        r, im = self.linear_read, self.linear_imag
+        if AG.grad_mode(x.buf, r.weight, r.bias, im.weight, im.bias):
+            obuf = AG.DenseFn.apply(self, AG._geom(x), (C_out, F_out), x.buf, r.weight, r.bias, im.weight, im.bias)
+            return Planar(obuf, C_out, F_out, x.B, x.T, x.Tp, x.Jp)
         pr, pi = self._packed()
         return ops.cdense(x, pr, pi, self.out_channel, C_out, F_out)
 

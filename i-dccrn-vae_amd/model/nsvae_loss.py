@@ -2,6 +2,7 @@
 ete_train_se_loss :755-806, two_phase_loss :809-948) on the HIP reduction kernels."""
 import torch
 
+from .. import autograd as AG
 from .. import ops
 from ._loss_common import kl_mean, latent_ref, recon_terms
 from .sisnr_loss import si_snr as _si_snr
@@ -10,6 +11,8 @@ from .sisnr_loss import si_snr as _si_snr
 def _miu_dist(miu_a, miu_b):
     pa, oa = latent_ref(miu_a, miu_a, miu_a) if getattr(miu_a, "_idv", None) is None else (miu_a._idv, (miu_a._idv_off,) * 3)
     pb, ob = latent_ref(miu_b, miu_b, miu_b) if getattr(miu_b, "_idv", None) is None else (miu_b._idv, (miu_b._idv_off,) * 3)
+    if AG.grad_mode(pa.buf, pb.buf):
+        return AG.MiuDistFn.apply(AG._geom(pa), oa[0], AG._geom(pb), ob[0], miu_a.shape[2], pa.buf, pb.buf)
     return ops.miu_dist(pa, oa[0], pb, ob[0], miu_a.shape[2])
 
 

@@ -17,6 +17,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from .. import autograd as AG
 from .. import ops
 from ..ops import Planar
 from .complex_progress import (ComplexBatchNormal, ComplexConv2d, ComplexConvTranspose2d, ComplexDense, ComplexLSTM,
@@ -48,7 +49,12 @@ class STFT(nn.Module):
     def planar(self, signal: torch.Tensor) -> Planar:
         _need_cuda(signal)
         T = 1 + signal.shape[1] // self.hop_length
-        return ops.stft(signal.float(), dft_plan(self.n_fft, self.win_length, self.hop_length, T, signal.device))
+        plan = dft_plan(self.n_fft, self.win_length, self.hop_length, T, signal.device)
+        if AG.grad_mode(signal):
+            sig = signal.float().contiguous()
+            buf = AG.StftFn.apply(plan, sig)
+            return Planar(buf, 1, plan.F, sig.shape[0], T, T + 1, Planar.jp_for(sig.shape[0], T + 1))
+        return ops.stft(signal.float(), plan)
 
     def forward(self, signal):
         pl = self.planar(signal)
@@ -65,7 +71,10 @@ class ISTFT(nn.Module):
         self.n_fft, self.hop_length, self.win_length = n_fft, hop_length, win_length
 
     def planar(self, spec: Planar) -> torch.Tensor:
-        return ops.istft(spec, dft_plan(self.n_fft, self.win_length, self.hop_length, spec.T, spec.buf.device))
+        plan = dft_plan(self.n_fft, self.win_length, self.hop_length, spec.T, spec.buf.device)
+        if AG.grad_mode(spec.buf):
+            return AG.IstftFn.apply(plan, AG._geom(spec), spec.buf)
+        return ops.istft(spec, plan)
 
     def forward(self, x):
         pl = getattr(x, "_idv", None)
@@ -82,6 +91,17 @@ class _Block(nn.Module):
 
     def _run(self, conv, x: Planar, train: bool, **kw) -> Planar:
         slope = self.prelu.weight.detach()
+        skip = kw.get("skip")
+        if train and AG.grad_mode(x.buf, skip.buf if skip is not None else None, *self.parameters()):
+            # training step: autograd.Function with the HIP backward kernels (conv + train-mode CBN + PReLU)
+            if kw.get("want", "planar") != "planar":
+                raise RuntimeError("split images are an eval-mode format")
+            div = kw.get("skip_div", 1)
+            if skip is not None and div > 1:
+                if skip.buf.requires_grad:
+                    raise NotImplementedError("gradient through repeated (num_samples) skip connections")
+                skip = ops.repeat_batch(skip, div)
+            return AG.conv_block(conv, self.bn, self.prelu.weight, x, skip, kw.get("zero_skip", False))
         if train:
             if kw.get("want", "planar") != "planar":
                 raise RuntimeError("split images are an eval-mode format (train-mode CBN normalises planar fp32 in place)")
@@ -127,6 +147,10 @@ class Decoder(_Block):
                        zero_skip: bool = False, want: str = "planar"):
         kw = dict(skip=skip, skip_div=skip_div, zero_skip=zero_skip, want=want)
         if not self.if_bn:
+            if AG.grad_mode(x.buf, skip.buf if skip is not None else None, *self.transconv.parameters()):
+                if skip is not None and skip_div > 1:
+                    skip = ops.repeat_batch(skip, skip_div)
+                return AG.conv_block(self.transconv, None, None, x, skip, zero_skip)
             return self.transconv.forward_planar(x, **kw)
         return self._run(self.transconv, x, train, **kw)
 
@@ -271,8 +295,14 @@ def _apply_datanorm(stft: Planar, mean, std) -> Planar:
 def _predict_outputs(module, out: Planar, stft_in: Planar, recon_type: str, x_div: int = 1):
     """Mask / real_imag branch shared by DCCRN_ and the decoders -> (pred planar, predict complex [B,F,T])."""
     if recon_type == "mask":
+        if AG.grad_mode(out.buf, stft_in.buf if x_div == 1 else None):
+            xb = stft_in.buf if x_div == 1 else stft_in.buf.detach()
+            pbuf, pcr = AG.MaskFn.apply(AG._geom(out), AG._geom(stft_in), x_div, out.buf, xb)
+            return ops.rewrap(pbuf, out), torch.view_as_complex(pcr)
         return ops.mask_apply(out, stft_in, x_div)
     if recon_type == "real_imag":
+        if AG.grad_mode(out.buf):
+            return out, torch.view_as_complex(AG.PlanarToComplexFn.apply(AG._geom(out), out.buf))
         return out, ops.planar_to_complex(out)
     raise ValueError(f"recon_type {recon_type!r}")
 
@@ -364,7 +394,12 @@ class _VAEEncoderBase(nn.Module):
         B, T, ns = lat.B, lat.T, self.num_samples
         if eps is None:
             eps = (torch.randn(B, ns, T, z, device=lat.buf.device), torch.randn(B, ns, T, z, device=lat.buf.device))
-        zp = ops.reparam(lat, (3 * z * k, 3 * z * k + z, 3 * z * k + 2 * z), z, eps[0], eps[1], ns)
+        off = (3 * z * k, 3 * z * k + z, 3 * z * k + 2 * z)
+        if AG.grad_mode(lat.buf):
+            zbuf = AG.ReparamFn.apply(AG._geom(lat), off, z, ns, lat.buf, eps[0], eps[1])
+            zp = Planar(zbuf, z, 1, B * ns, T, lat.Tp, Planar.jp_for(B * ns, lat.Tp))
+        else:
+            zp = ops.reparam(lat, off, z, eps[0], eps[1], ns)
         v = zp.channel_slice(0, z)                                  # [B*ns, T, zdim, 2]
         v._idv = zp
         return v

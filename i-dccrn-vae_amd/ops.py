@@ -501,6 +501,20 @@ class DftPlan:
         self.inv = pack_pw(w_inv, None)
         self.fwd16 = pack_pw_bf16(w_fwd)          # split-bf16 fragments of the same matrices (bf16x3 mode)
         self.inv16 = pack_pw_bf16(w_inv)
+        self._w_fwd, self._w_inv = w_fwd, w_inv
+        self._fwd_T = self._inv_T = None
+
+    def fwd_T(self):
+        """Packed transposed DFT matrix [win][2F]: the adjoint (signal gradient) of the STFT contraction."""
+        if self._fwd_T is None:
+            self._fwd_T = pack_pw(self._w_fwd.t().contiguous(), None)
+        return self._fwd_T
+
+    def inv_T(self):
+        """Packed transposed inverse-DFT matrix [2F][win]: the adjoint (spectrum gradient) of the ISTFT contraction."""
+        if self._inv_T is None:
+            self._inv_T = pack_pw(self._w_inv.t().contiguous(), None)
+        return self._inv_T
 
 
 def stft(x: torch.Tensor, plan: DftPlan, Tp: Optional[int] = None) -> Planar:
@@ -584,8 +598,20 @@ def reparam(lat: Planar, off, zdim: int, eps_r, eps_i, ns: int) -> Planar:
 
 
 # ----------------------------------------------------------------------------- losses
+def check_dev_f32(t: torch.Tensor, name: str, device=None):
+    """The kernels dereference raw pointers: a CPU tensor (e.g. straight out of a DataLoader) must fail here, not on the GPU."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise L.IdvError(f"{name}: expected a CUDA (ROCm) tensor, got {type(t).__name__} on "
+                         f"{getattr(t, 'device', '?')}; the HIP hot path has no CPU fallback")
+    if device is not None and t.device != torch.device(device):
+        raise L.IdvError(f"{name}: on {t.device}, expected {device}")
+
+
 def sisnr(source: torch.Tensor, est: torch.Tensor, src_div: int = 1) -> torch.Tensor:
     B, Ln = est.shape
+    check_dev_f32(source, "source", est.device)
+    if source.dtype != torch.float32 or est.dtype != torch.float32 or source.shape[-1] < Ln:
+        raise L.IdvError("sisnr: float32 tensors with source length >= estimate length expected")
     assert source.stride(-1) == 1 and est.stride(-1) == 1
     work = torch.empty(3 * B, dtype=torch.float64, device=est.device)
     out = torch.empty(1, dtype=torch.float32, device=est.device)
@@ -598,7 +624,12 @@ def recon_loss(pred_c: torch.Tensor, ori: torch.Tensor, ori_div: int = 1):
     """pred_c: complex64 [B,F,T] (contiguous); ori: [B/ori_div, F, T, 2] real, any strides -> (cpx, mag)."""
     pr = torch.view_as_real(pred_c)
     assert pr.is_contiguous()
+    check_dev_f32(ori, "ori_cpx_stft", pr.device)
+    if ori.dtype != torch.float32:
+        raise L.IdvError("recon_loss: float32 STFT expected")
     B, F, T, _ = pr.shape
+    if tuple(ori.shape[1:]) != (F, T, 2):
+        raise L.IdvError(f"recon_loss: STFT shape {tuple(ori.shape)} does not match the prediction {tuple(pr.shape)}")
     work = torch.empty(3, dtype=torch.float64, device=pr.device)
     out = torch.empty(2, dtype=torch.float32, device=pr.device)
     sb, sf, st, sr = ori.stride()
@@ -636,3 +667,184 @@ def cbn_apply(act: Planar, fold: torch.Tensor, slope=None):
     call("idv_cbn_apply_prelu", act.ptr(), p(fold), p(slope), i(act.C), i(act.F), i(act.B), i(act.Tp), i(act.Jp), i(act.T),
          stream_ptr())
     return act
+
+
+# ----------------------------------------------------------------------------- backward (gradient) operators
+# Thin wrappers over the idv_*_bwd entries; autograd.py strings them into torch.autograd.Function classes.
+_LL = L._L
+
+
+def _ll_fn(name):
+    fn = getattr(L.lib(), name)
+    fn.restype = _LL
+    return fn
+
+
+def like(x: Planar, C: Optional[int] = None, F: Optional[int] = None, zero=False) -> Planar:
+    return Planar.empty(x.C if C is None else C, x.F if F is None else F, x.B, x.T, x.Tp, x.buf.device, zero=zero)
+
+
+def rewrap(buf: torch.Tensor, x: Planar, C: Optional[int] = None, F: Optional[int] = None) -> Planar:
+    """A Planar with x's geometry over another flat buffer (e.g. an incoming gradient)."""
+    return Planar(buf, x.C if C is None else C, x.F if F is None else F, x.B, x.T, x.Tp, x.Jp)
+
+
+def pack_cconv_adjoint(w_re, w_im, cout: int, cin_total: int, cin_used: int, transposed: bool):
+    """Fragments of the adjoint operator (data gradient), see idv_pack_cconv_adjoint; arguments describe the adjoint."""
+    cck = L.lib().idv_cconv_cck(cin_used)
+    ccp = (2 * cin_used + cck - 1) // cck * cck
+    mt = mtiles_alloc(2 * cout)
+    wfrag = torch.empty(mt * ccp * 5 * 64, dtype=torch.float32, device=w_re.device)
+    bias = torch.empty(mt * 32, dtype=torch.float32, device=w_re.device)
+    call("idv_pack_cconv_adjoint", p(w_re), p(w_im), i(cout), i(cin_total), i(cin_used), i(1 if transposed else 0), p(wfrag),
+         p(bias), stream_ptr())
+    return wfrag, bias
+
+
+def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, causal: bool) -> Planar:
+    """Data gradient of a causal_complex_conv2d / causal_ComplexConvTranspose2d: the adjoint operator on idv_cconv2d_fwd
+    (transposed conv reading (dy[t+1], dy[t]) / conv reading (dy[t], dy[t+1]); all T frames kept: column T+1 is the next
+    utterance's zero guard column)."""
+    if not causal:
+        raise NotImplementedError("data gradients are implemented for the causal blocks")
+    adj_transposed = not fwd_transposed
+    Fout = 2 * dy.F - 1 if adj_transposed else (dy.F - 1) // 2 + 1
+    out = Planar.empty(cout_adj, Fout, dy.B, dy.T, dy.Tp, dy.buf.device)
+    call("idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(wfrag), p(bias), p(None), out.ptr(), p(None),
+         i(1 if adj_transposed else 0), i(0), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(dy.T), stream_ptr())
+    return out
+
+
+_WORK = {}
+
+
+def _scratch(n: int, device, tag="w") -> torch.Tensor:
+    """Grow-only fp32 scratch per (device, stream, tag): weight-gradient partials, reused across layers and steps."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream, tag)
+    t = _WORK.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(bucket(n), dtype=torch.float32, device=device)
+        _WORK[key] = t
+    return t
+
+
+def cconv_wgrad(x: Planar, ci_off: int, dy: Planar, cout: int, cin_total: int, transposed: bool, causal: bool, dw_re, dw_im):
+    tshift = -1 if (causal or transposed) else 0
+    cs, cl = (x.C, cout) if transposed else (cout, x.C)
+    n = int(_ll_fn("idv_cconv_wgrad_work_floats")(i(cs), i(cl), i(x.B), i(x.Tp)))
+    work = _scratch(n, x.buf.device)
+    call("idv_cconv2d_bwd_weight", x.ptr(), i(x.C), i(ci_off), dy.ptr(), i(cout), i(cin_total), i(1 if transposed else 0),
+         i(tshift), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(dy.Jp), p(work), ll(work.numel()), p(dw_re), p(dw_im), stream_ptr())
+
+
+def cconv_bias_grad(dy: Planar):
+    stats = cbn_stats(dy)
+    db_re = torch.empty(dy.C, dtype=torch.float32, device=dy.buf.device)
+    db_im = torch.empty_like(db_re)
+    call("idv_cconv2d_bwd_bias", p(stats), i(dy.C), p(db_re), p(db_im), stream_ptr())
+    return db_re, db_im
+
+
+def cbn_apply_to(y: Planar, fold, slope) -> Planar:
+    out = like(y)
+    call("idv_cbn_apply_prelu_to", y.ptr(), p(fold), p(slope), i(y.C), i(y.F), i(y.B), i(y.Tp), i(y.Jp), i(y.T), out.ptr(),
+         stream_ptr())
+    return out
+
+
+# Data-parallel training hook (parallel.py): when set, called on the per-channel moment sums of every train-mode
+# ComplexBatchNormal (forward: [C][5] doubles, backward: [C][8] doubles) to all-reduce them over the ranks; returns
+# the world size so the element count becomes the global one.
+BN_SYNC = None
+
+
+def cbn_bwd(dz: Planar, y: Planar, fold, moments, bn, slope, count: float):
+    """-> (dy, d gamma_rr, d gamma_ri, d gamma_ii, d beta_r, d beta_i, dslope[1])"""
+    C, dev = y.C, y.buf.device
+    sums = torch.empty(C, 8, dtype=torch.float64, device=dev)
+    call("idv_cbn_bwd_reduce", dz.ptr(), y.ptr(), p(fold), p(slope), i(C), i(y.F), i(y.B), i(y.Tp), i(y.Jp), i(y.T), p(sums),
+         stream_ptr())
+    if BN_SYNC is not None:
+        count = count * BN_SYNC(sums)
+    coef = torch.empty(C, 12, dtype=torch.float32, device=dev)
+    g = [torch.empty(C, dtype=torch.float32, device=dev) for _ in range(5)]
+    dslope = torch.zeros(1, dtype=torch.float32, device=dev)
+    call("idv_cbn_bwd_finalize", p(sums), d(count), p(moments), p(bn[0]), p(bn[1]), p(bn[2]), i(C), p(coef), p(g[0]), p(g[1]),
+         p(g[2]), p(g[3]), p(g[4]), p(dslope if slope is not None else None), stream_ptr())
+    dy = like(y)
+    call("idv_cbn_bwd_apply", dz.ptr(), y.ptr(), p(fold), p(coef), p(slope), i(C), i(y.F), i(y.B), i(y.Tp), i(y.Jp), i(y.T),
+         dy.ptr(), stream_ptr())
+    return (dy, *g, dslope)
+
+
+def cbn_finalize(stats, count: float, bn_mod, first_call: bool, momentum: float, update_running: bool = True):
+    """stats -> (moments [5, C], fold [C, 6]); running buffers of bn_mod updated in place."""
+    C = bn_mod.C
+    dev = stats.device
+    if BN_SYNC is not None:
+        count = count * BN_SYNC(stats)
+    moments = torch.empty(5, C, dtype=torch.float32, device=dev)
+    fold = torch.empty(C, 6, dtype=torch.float32, device=dev)
+    rb = (bn_mod.running_mean_real, bn_mod.running_mean_imag, bn_mod.Vrr, bn_mod.Vri, bn_mod.Vii) if update_running else (None,) * 5
+    call("idv_cbn_finalize", p(stats), d(count), p(bn_mod.gamma_rr), p(bn_mod.gamma_ri), p(bn_mod.gamma_ii), p(bn_mod.beta_r),
+         p(bn_mod.beta_i), i(C), i(1 if first_call else 0), f(momentum), p(rb[0]), p(rb[1]), p(rb[2]), p(rb[3]), p(rb[4]),
+         p(moments), p(fold), stream_ptr())
+    return moments, fold
+
+
+def pw_wgrad(dout_ptr, M: int, Jp_d: int, x_ptr, K: int, Jp_x: int, J: int, dw: torch.Tensor, *, shift=0, rowmap=0, H=0,
+             accumulate=False):
+    n = int(_ll_fn("idv_pw_wgrad_work_floats")(i(M), i(K), i(J)))
+    work = _scratch(n, dw.device)
+    call("idv_pw_bwd_weight", dout_ptr, i(M), i(Jp_d), x_ptr, i(K), i(Jp_x), i(J), i(shift), p(work), ll(work.numel()), p(dw),
+         i(dw.stride(0)), i(rowmap), i(H), i(1 if accumulate else 0), stream_ptr())
+
+
+def planar_rowsum(x_ptr, M: int, Jp: int, J: int, out: torch.Tensor, accumulate=False):
+    call("idv_planar_rowsum", x_ptr, i(M), i(Jp), i(J), i(1 if accumulate else 0), p(out), stream_ptr())
+
+
+def mask_apply_bwd(mask: Planar, X: Planar, x_div: int, dpred: Optional[Planar], dpred_c, want_dx: bool = False):
+    dm = like(mask)
+    dX = like(X) if want_dx else None
+    call("idv_mask_apply_bwd", mask.ptr(), X.ptr(), i(x_div), i(X.Jp), dpred.ptr() if dpred is not None else p(None),
+         p(dpred_c), i(mask.F), i(mask.B), i(mask.T), i(mask.Tp), i(mask.Jp), dm.ptr(), dX.ptr() if dX is not None else p(None),
+         stream_ptr())
+    return dm, dX
+
+
+def complex_to_planar(xc: torch.Tensor, Tp: Optional[int] = None) -> Planar:
+    """interleaved float [B, F, T, 2] -> planar [2][1][F][Jp]"""
+    B, F, T, _ = xc.shape
+    out = Planar.empty(1, F, B, T, Tp or T + 1, xc.device)
+    call("idv_complex_to_planar", p(xc.contiguous()), out.ptr(), i(F), i(B), i(T), i(out.Tp), i(out.Jp), stream_ptr())
+    return out
+
+
+def istft_bwd(dy: torch.Tensor, spec: Planar, plan: "DftPlan") -> Planar:
+    """d loss / d spec of ops.istft."""
+    B, T = spec.B, spec.T
+    dfr = Planar.empty(1, plan.win // 2, B, T, spec.Tp, dy.device)
+    call("idv_istft_ola_bwd", p(dy.contiguous()), p(plan.env_inv), i(B), i(plan.n_fft), i(plan.win), i(plan.hop), i(T),
+         i(spec.Tp), i(dfr.Jp), dfr.ptr(), stream_ptr())
+    out = like(spec)
+    wT = plan.inv_T()
+    pw_gemm(dfr.ptr(), plan.win, wT[0], wT[1], 2 * plan.F, B, spec.Tp, dfr.Jp, T, out.ptr())
+    return out
+
+
+def stft_bwd(dX: Planar, plan: "DftPlan", Lx: int) -> torch.Tensor:
+    """d loss / d signal of ops.stft."""
+    B, T = dX.B, dX.T
+    dfr = Planar.empty(1, plan.win // 2, B, T, dX.Tp, dX.buf.device)
+    wT = plan.fwd_T()
+    pw_gemm(dX.ptr(), 2 * plan.F, wT[0], wT[1], plan.win, B, dX.Tp, dX.Jp, T, dfr.ptr())
+    dx = torch.empty(B, Lx, dtype=torch.float32, device=dX.buf.device)
+    call("idv_stft_frames_bwd", dfr.ptr(), i(B), i(Lx), i(plan.n_fft), i(plan.win), i(plan.hop), i(T), i(dX.Tp), i(dfr.Jp),
+         p(dx), stream_ptr())
+    return dx
+
+
+def reparam_bwd(lat: Planar, off, zdim: int, eps_r, eps_i, ns: int, dz: Planar, dlat: Planar):
+    call("idv_reparam_bwd", lat.ptr(), i(lat.C), i(off[0]), i(off[1]), i(off[2]), i(zdim), p(eps_r), p(eps_i), i(ns), i(lat.B),
+         i(lat.T), i(lat.Tp), i(lat.Jp), dz.ptr(), i(dz.Jp), dlat.ptr(), stream_ptr())

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IDV_ABI_VERSION 1
+#define IDV_ABI_VERSION 2
 #define IDV_SLACK_FLOATS 256
 
 int idv_abi_version(void);
@@ -177,6 +177,12 @@ int idv_planar_to_complex(const float* act, float* out_c, int F, int B, int T, i
  * imag = ir + ri.  x: planar [2][K][Jp]; out: planar [2][H][Jp].  flags bit 0: split-bf16 recurrence (H = 128).  wihN / bihN: idv_pack_lstm_ih of layer
  * N, whhN: idv_pack_lstm_hh of layer N.  work: idv_clstm_work_floats(H, B, T, Jp) floats. */
 long long idv_clstm_work_floats(int H, int B, int T, int Jp);   /* 24*T*B*H + 4*B*H + 4*H*Jp */
+/* flags bit 2 (training forward, exact-fp32 recurrence only): the activated gates (i, f, g, o) and the cell states are kept
+ * for idv_lstm_bptt.  work then holds idv_clstm_train_work_floats floats, laid out (TBH = T*B*H)
+ *   [G0 16 TBH | G1 16 TBH | h0 4 TBH | h1 4 TBH | c0 4 TBH | c1 4 TBH | scratch]
+ * G0: [z][T*B][8H] (z = real / imag input; columns [weight set s][4H]), G1: [run = 2z+s][T*B][4H], h/c: [run][T*B][H];
+ * gate columns are ordered colp = ((u/16)*4 + gate)*16 + u%16. */
+long long idv_clstm_train_work_floats(int H, int B, int T, int Jp);   /* 48*T*B*H + 4*B*H + 4*H*Jp */
 int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0, const float* wih1,
                   const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp, float* work, float* out,
                   int flags, void* stream);
@@ -232,6 +238,111 @@ int idv_ckl(const float* q1, int H1, int Jp1, int o1_miu, int o1_ls, int o1_dl, 
 /* miu_dis_loss term (model/nsvae_loss.py:349-360): sqrt(sum_{h,ri} mean_{b,t} (miu1 - miu2)^2). */
 int idv_miu_dist(const float* q1, int H1, int Jp1, int off1, const float* q2, int H2, int Jp2, int off2, int zdim,
                  int B, int T, int Tp, double* work, float* out, void* stream);
+
+/* ==== backward (gradient) entry points =========================================================================
+ * The reference has no backward code of its own: torch.autograd differentiates the stock operators behind
+ * `loss.backward()` in its train steps (supervised_dccrn/train.py:239-243, i_dccrn_vae/pretrained_vaes/train.py:296-301,
+ * i_dccrn_vae/nsvae_dccrn/train_nsvae.py:557-561, train_second_phase_decoder.py:420-433).  Each entry below is the
+ * gradient of the forward entry it names, for the same reference lines.  Planar gradients keep the layout invariant
+ * (guard columns zero).  Data gradients of the conv blocks reuse idv_cconv2d_fwd with the adjoint weights. */
+
+/* Adjoint weights for the DATA gradient of ComplexConv2d / ComplexConvTranspose2d (complex_progress.py:16-22, :244-250):
+ * the parameter tensor read with the other layout (conv [Cout][Cin] as transposed-conv [Cin' = Cout][Cout' = Cin] and vice
+ * versa), imaginary part negated, zero bias.  `transposed` / Cout / Cin_* describe the adjoint operator, which is then run by
+ * idv_cconv2d_fwd: transposed = 1, tshift = 0 for the causal conv's gradient; transposed = 0, tshift = 0 and
+ * t_valid_out = T for the causal transposed conv's. */
+int idv_pack_cconv_adjoint(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used, int transposed,
+                           float* wfrag, float* bias_out, void* stream);
+
+/* WEIGHT gradient of idv_cconv2d_fwd for one source of the channel concat (x: planar [2][Cx][Fin][Jp_x] = channels
+ * ci_off .. ci_off+Cx of the weight tensor; dy: planar [2][Cout][Fout][Jp_dy], the gradient at the conv output, i.e. after
+ * idv_cbn_bwd_apply in a train-mode block).  Writes dw_re / dw_im entries [*, ci_off:ci_off+Cx] (conv [Cout][Cin_total][5][2])
+ * or [ci_off:ci_off+Cx, *] (transposed [Cin_total][Cout][5][2]).  Split-K over the B*Tp columns with deterministic
+ * two-stage summation; work: idv_cconv_wgrad_work_floats(Cs, Cl, B, Tp) floats with (Cs, Cl) = (Cout, Cx) for a conv and
+ * (Cx, Cout) for a transposed conv.  tshift as in idv_cconv2d_fwd. */
+long long idv_cconv_wgrad_work_floats(int Cs, int Cl, int B, int Tp);
+int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const float* dy, int Cout, int Cin_total, int transposed,
+                           int tshift, int Fin, int B, int Tp, int Jp_x, int Jp_dy, float* work, long long work_floats,
+                           float* dw_re, float* dw_im, void* stream);
+/* bias gradients (b_re enters real as +, imag as +; b_im real as -, imag as +; complex_progress.py:16-18) from
+ * idv_cbn_stats(dy): db_re = sum dy_r + sum dy_i, db_im = sum dy_i - sum dy_r. */
+int idv_cconv2d_bwd_bias(const double* stats_dy, int Cout, float* db_re, float* db_im, void* stream);
+
+/* Weight gradient of idv_pw_gemm (ComplexDense complex_progress.py:83-89; nn.LSTM weight_ih / weight_hh :45-48):
+ * dw[rowmap(m)][k] (+)= sum_j dout[m][j] * x[k][j + shift]; dout / x planar rows of stride Jp_d / Jp_x; shift = -1 pairs
+ * every column with its left neighbour (h_{t-1} of the recurrent weights; the guard column supplies h_{-1} = 0).
+ * rowmap 1: rows arrive in the recurrent kernels' gate order (colp) and are written in torch's (gate*H + unit), M a
+ * multiple of 4H.  work: idv_pw_wgrad_work_floats(M, K, J). */
+long long idv_pw_wgrad_work_floats(int M, int K, int J);
+int idv_pw_bwd_weight(const float* dout, int M, int Jp_d, const float* x, int K, int Jp_x, int J, int shift, float* work,
+                      long long work_floats, float* dw, int ldw, int rowmap, int H, int accumulate, void* stream);
+int idv_planar_rowsum(const float* x, int M, int Jp, int J, int accumulate, float* out, void* stream);   /* bias gradients */
+
+/* Train-mode ComplexBatchNormal + PReLU (complex_progress.py:131-209, pvae_module.py:64-68, :88-93).
+ * idv_cbn_apply_prelu_to: out-of-place idv_cbn_apply_prelu (training keeps the conv output y for the backward pass).
+ * Backward, three steps: idv_cbn_bwd_reduce (per-channel sums [C][8] doubles of du = dz*PReLU'(u), du (x) y and the PReLU
+ * slope term; data-parallel training all-reduces these), idv_cbn_bwd_finalize (moments = the [5][C] output of
+ * idv_cbn_finalize, count = B*F*T of the whole batch; -> coef[C][12], d gamma_rr/ri/ii, d beta_r/i, dslope[1]),
+ * idv_cbn_bwd_apply (dy = Z^T du + A (y - mu) + c). */
+int idv_cbn_apply_prelu_to(const float* y, const float* fold, const float* prelu_slope, int C, int F, int B, int Tp, int Jp,
+                           int t_valid, float* out, void* stream);
+int idv_cbn_bwd_reduce(const float* dz, const float* y, const float* fold, const float* prelu_slope, int C, int F, int B,
+                       int Tp, int Jp, int t_valid, double* sums, void* stream);
+int idv_cbn_bwd_finalize(const double* sums, double count, const float* moments, const float* gamma_rr, const float* gamma_ri,
+                         const float* gamma_ii, int C, float* coef, float* dgamma_rr, float* dgamma_ri, float* dgamma_ii,
+                         float* dbeta_r, float* dbeta_i, float* dslope, void* stream);
+int idv_cbn_bwd_apply(const float* dz, const float* y, const float* fold, const float* coef, const float* prelu_slope, int C,
+                      int F, int B, int Tp, int Jp, int t_valid, float* dy, void* stream);
+
+/* idv_mask_apply backward (pvae_module.py:224-234): gradient w.r.t. the mask from the gradients of the planar prediction
+ * and / or of the interleaved complex64 tensor (either may be NULL); dX (optional, x_div == 1 only): gradient w.r.t. the
+ * input spectrum, needed when the waveform itself requires grad. */
+int idv_mask_apply_bwd(const float* mask, const float* X, int x_div, int JpX, const float* dpred, const float* dpred_c, int F,
+                       int B, int T, int Tp, int Jp, float* dmask, float* dX, void* stream);
+/* interleaved [B][F][T][2] -> planar [2][F][Jp] (adjoint of idv_planar_to_complex; also packs a caller's complex tensor). */
+int idv_complex_to_planar(const float* in_c, float* act, int F, int B, int T, int Tp, int Jp, void* stream);
+/* idv_istft_ola backward (pvae_module.py:38-42): dy[B][hop*(T-1)] -> dframes[win][Jp]; the inverse-DFT adjoint is idv_pw_gemm
+ * with the transposed matrix. */
+int idv_istft_ola_bwd(const float* dy, const float* env_inv, int B, int n_fft, int win, int hop, int T, int Tp, int Jp,
+                      float* dframes, void* stream);
+/* idv_stft_frames backward (pvae_module.py:21-27, reflect padding included): dframes[win][Jp] -> dx[B][L]. */
+int idv_stft_frames_bwd(const float* dframes, int B, int L, int n_fft, int win, int hop, int T, int Tp, int Jp, float* dx,
+                        void* stream);
+/* idv_reparam backward (pvae_module.py:1832-1886): dz planar [2][zdim][Jpz] -> += on the (miu, log_sigma, delta) channels of
+ * dlat planar [2][Hl][Jp] (caller zeroes it). */
+int idv_reparam_bwd(const float* lat, int Hl, int off_miu, int off_ls, int off_dl, int zdim, const float* eps_r,
+                    const float* eps_i, int ns, int B, int T, int Tp, int Jp, const float* dz, int Jpz, float* dlat, void* stream);
+
+/* Loss gradients.  grad_out / g_*: device scalars (the incoming gradient of the loss value).
+ * idv_sisnr_bwd: work = the 3*B doubles idv_sisnr left behind; dest[B][L] = d loss / d estimate (sisnr_loss.py:7-19).
+ * idv_recon_loss_bwd: d(loss_cpx, loss_mag) / d pred_c (nsvae_loss.py:775-797).
+ * idv_ckl_bwd: d KL / d q1, += into dq1 (same layout as q1) (nsvae_loss.py:275-328, pretrain_pvaes_loss.py:225-281).
+ * idv_miu_dist_bwd: loss_value = the forward result; += into dq1 and / or dq2 (nsvae_loss.py:349-360). */
+int idv_sisnr_bwd(const float* source, int src_ld, int src_div, const float* est, int est_ld, int B, int L, const double* work,
+                  const float* grad_out, float* dest, void* stream);
+int idv_recon_loss_bwd(const float* pred_c, const float* ori, long long sb, long long sf, long long st, long long sr,
+                       int ori_div, int B, int F, int T, const float* g_cpx, const float* g_mag, float* dpred_c, void* stream);
+int idv_ckl_bwd(const float* q1, int H1, int Jp1, int o1_miu, int o1_ls, int o1_dl, const float* q2, int H2, int Jp2,
+                int o2_miu, int o2_ls, int o2_dl, int zdim, float eps, int B, int T, int Tp, const float* grad_out, float* dq1,
+                void* stream);
+int idv_miu_dist_bwd(const float* q1, int H1, int Jp1, int off1, const float* q2, int H2, int Jp2, int off2, int zdim, int B,
+                     int T, int Tp, const float* grad_out, const float* loss_value, float* dq1, float* dq2, void* stream);
+
+/* ComplexLSTM backward (complex_progress.py:50-74), building blocks driven by the host mirror (ops.clstm_bwd):
+ * idv_lstm_uncombine: planar output gradient -> per-run dh[4][T*B][H] (real = run0 - run3, imag = run2 + run1);
+ * idv_pack_lstm_hh_bwd: W_hh [4H][H] x 2 -> fragments for the (16 x 4H) x (4H x H) step contraction, 2*4H*H floats;
+ * idv_lstm_bptt: back-propagation through time of one layer, one launch per step; `gates` (activated i,f,g,o from the
+ *   training forward, addressing as G0 / G1 above) is overwritten with the pre-activation gate gradients;
+ *   work: idv_lstm_bptt_work_floats(H, B);
+ * idv_rows_to_planar: src[(t*B + b)*ld + c0 + u] -> planar dst[u][b*Tp + t + 1] (guard columns zeroed);
+ * idv_lstm_bias_grad: db[gate*H + unit] (+)= sum_j dGp[colp][j] for 4H planar rows. */
+int idv_lstm_uncombine(const float* dout, int H, int B, int T, int Tp, int Jp, float* dh, void* stream);
+int idv_pack_lstm_hh_bwd(const float* w_hh_re, const float* w_hh_im, int H, float* whhT, void* stream);
+long long idv_lstm_bptt_work_floats(int H, int B);
+int idv_lstm_bptt(float* gates, long long g_run_z, long long g_run_s, int ldg, const float* cstates, const float* dhout,
+                  const float* whhT, int H, int B, int T, float* work, void* stream);
+int idv_rows_to_planar(const float* src, long long ld, int c0, int ncol, int B, int T, int Tp, int Jp, float* dst, void* stream);
+int idv_lstm_bias_grad(const float* dGp, int H, int Jp, int J, int accumulate, float* db, void* stream);
 
 #ifdef __cplusplus
 }
