@@ -330,7 +330,11 @@ def check_grads(d, prefix, module, tol=1e-3):
     return worst
 
 
-def check_adam(d, prefix, module, lr=1e-3, wd=1e-3, tol=1e-3):
+def check_adam(d, prefix, module, lr=1e-3, wd=1e-3, tol=1e-2):
+    """One Adam step reproduces the reference's updated weights.  The first Adam step is lr * g / (|g| + 1e-8): sign-like,
+    so an element whose gradient is of the order of the 1e-8 epsilon (or of fp32 rounding noise) moves by a different
+    fraction of lr on the two sides even when the gradients agree to 1e-4 -- hence 1e-2 on the update vector (the
+    gradients themselves are held to 1e-3 by check_grads)."""
     params = [p_ for p_ in module.parameters() if p_.grad is not None]
     before = {k: p_.detach().clone() for k, p_ in module.named_parameters()}
     torch.optim.Adam(params, lr=lr, weight_decay=wd).step()
