@@ -10,9 +10,17 @@ One step = one pass of the hot path over one batch of synthetic utterances resid
   without the backward pass.  Utterances are independent: each rank runs its own batch (replicas, no collective
   on the data path); value = all ranks' utterances / max-over-ranks time.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant cgemm instantiation, HIP-event timed on the launching
-stream inside the timed region) and `cpu_baseline` (the torch-CPU oracle on the host cores, N = 1 only).
-Other workloads: --workload cvae_elbo | nsvae_kl | twophase (BASELINE.json configs 2, 3, 5, forward + loss).
+Prints ONE JSON line (rank 0) with `roofline` (dominant contraction kernel, HIP-event timed on the launching stream
+inside the timed region) and `cpu_baseline` (the reference's op sequence on stock torch-CPU operators, oracle/stock_cpu.py,
+N = 1 only).  The headline is measured at the reference's precision (`dtype` "f32": exact fp32 MFMA, one stream); the
+split-bf16 mode is attached as the clearly labelled secondary record `alt` (same workload, `dtype` "bf16x3"), together with
+a two-stream run of it whose output is compared bit for bit with the one-stream output (`two_stream_bit_exact`).
+
+Other workloads (--workload): cvae_elbo | nsvae_kl | twophase (BASELINE.json configs 2, 3, 5: forward + loss) and the
+TRAIN steps forward + loss + backward + Adam, as the reference's trainers run them: dccrn_cl_train
+(supervised_dccrn/train.py:233-243), cvae_train (pretrained_vaes/train.py:281-301), nsvae_train (train_nsvae.py:487-574,
+config 4) and twophase_train (train_second_phase_decoder.py:376-433, config 5).  With N > 1 the train steps shard the
+global batch, all-reduce the batch-norm moment sums (Sync-CBN) and average the gradients over RCCL (parallel.py).
 """
 from __future__ import annotations
 
@@ -108,6 +116,84 @@ def build_workload(name, B, device, rank):
             return loss.phase_2_loss(pred, s[11], clean, recon, None, None, None, None)[0]
         return step, B, {"workload": "two-phase decoder fine-tune forward: frozen NSVAE encoder + decoder(mask, pad='sig') + SI-SNR",
                          "batch_per_gpu": B}
+    par = importlib.import_module("i-dccrn-vae_amd.parallel")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    def train_step(models, fwd_loss):
+        """zero_grad -> forward + loss -> backward -> [gradient all-reduce] -> Adam.step (lr 1e-3, weight_decay 1e-3:
+        supervised_dccrn/train.py:109)."""
+        params = [p_ for m in models for p_ in m.parameters() if p_.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-3)
+        red = par.GradAllReduce(params) if world > 1 else None
+        if world > 1:
+            par.enable_sync_bn()
+
+        def step():
+            with torch.enable_grad():
+                opt.zero_grad(set_to_none=True)
+                loss = fwd_loss()
+                loss.backward()
+            if red is not None:
+                red.reduce()
+            opt.step()
+            return loss.detach()
+        return step
+
+    if name == "dccrn_cl_train":
+        model = synth_state(pm.DCCRN_(NFFT, HOP, np_, True, device, WIN, SKIP, "mask", False, None, None), 51).to(device)
+        model.train()
+        loss = nl.ete_train_se_loss([0.0, 0.0, 1.0])
+
+        def fl():
+            est, est_stft = model(noisy, train=True)
+            return loss.final_ete_loss(est_stft, model.stft(clean), clean, est)[0]
+        return train_step([model], fl), B, {"workload": "supervised DCCRN-CL TRAIN step: forward(train=True) + final_ete_loss "
+                                            "(weights 0/0/1) + backward + Adam", "batch_per_gpu": B}
+    if name == "cvae_train":
+        ns, zdim = 5, 128
+        enc = synth_state(pm.pvae_dccrn_encoder_skip_prepare(np_, True, device, zdim, NFFT, HOP, WIN, ns), 52).to(device)
+        dec = synth_state(pm.pvae_dccrn_decoder_skip_prepare(np_, True, device, ns, zdim, NFFT, HOP, WIN, "real_imag", SKIP), 53).to(device)
+        loss = pl.complex_standard_vae_loss(torch.ones(1), 1.0, 0.0, 'multiple', 'real_imag', [1.0, 1.0, 0.0], ns)
+
+        def fl():
+            z, miu, ls, dl, skiper, C, F, stft_x = enc(clean, train=True)
+            recon, pred = dec(stft_x, z, skiper, C, F, train=True)
+            return loss.cal_loss(clean, recon, stft_x.detach(), pred, miu, ls, dl, z, 100)[0]
+        return train_step([enc, dec], fl), B, {"workload": "CVAE pre-training TRAIN step: encoder + decoder (num_samples=5) + ELBO "
+                                               "+ backward + Adam", "batch_per_gpu": B}
+    if name == "nsvae_train":
+        ns, zdim = 2, 128
+        ce = synth_state(pm.pvae_dccrn_encoder_skip_prepare(np_, True, device, zdim, NFFT, HOP, WIN, ns), 54).to(device)
+        ne = synth_state(pm.pvae_dccrn_encoder_skip_prepare(np_, True, device, zdim, NFFT, HOP, WIN, ns), 55).to(device)
+        se = synth_state(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, device, zdim, NFFT, HOP, WIN, ns, 2), 56).to(device)
+        for m_ in (ce, ne):
+            for p_ in m_.parameters():
+                p_.requires_grad = False
+        loss = nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.0, zdim, ns, 2, 'original', 'False', SKIP, 'both')
+
+        def fl():
+            with torch.no_grad():
+                c = ce(clean, train=False)
+                n = ne(noise, train=False)
+            s = se(noisy, train=True)
+            return loss.final_nsvae_loss(c[1], n[1], s[1], s[5], c[2], n[2], s[2], s[6], c[3], n[3], s[3], s[7],
+                                         s[0], s[4], c[4], n[4], s[8])[0]
+        return train_step([se], fl), B, {"workload": "NSVAE TRAIN step (config 4): 2 frozen encoders (eval) + noisy encoder "
+                                         "(train, latent_num=2) + nsvae KL loss + backward + Adam", "batch_per_gpu": B}
+    if name == "twophase_train":
+        ns, zdim = 2, 128
+        se = synth_state(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, device, zdim, NFFT, HOP, WIN, ns, 2), 56).to(device)
+        dec = synth_state(pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, device, ns, zdim, NFFT, HOP, WIN, "mask", True, SKIP, False), 57).to(device)
+        for p_ in se.parameters():
+            p_.requires_grad = False
+        loss = nl.two_phase_loss([0, 0, 1], 1.0, zdim, 1)
+
+        def fl():
+            s = se(noisy, train=False)
+            recon, pred = dec(s[11], s[0], s[8], s[9], s[10], train=True, pad='sig')
+            return loss.phase_2_loss(pred, s[11], clean, recon, None, None, None, None)[0]
+        return train_step([dec], fl), B, {"workload": "decoder fine-tune TRAIN step (config 5): frozen NSVAE encoder (eval) + "
+                                          "decoder(mask, pad='sig', train) + SI-SNR + backward + Adam", "batch_per_gpu": B}
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -124,11 +210,13 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The CPU oracle (torch-CPU restatement of the reference's op sequence, MKLDNN convolutions, all host
-    cores) on a bounded sample of the SAME workload: B = 2 utterances per pass."""
+def cpu_baseline(seconds_budget=20.0, train=False):
+    """The reference's op sequence on STOCK torch-CPU operators (nn.Conv2d / nn.ConvTranspose2d on MKLDNN, the fused CPU
+    nn.LSTM, torch.stft / istft; oracle/stock_cpu.py, pinned to the oracle in tests/test_host_cpu.py) on a bounded sample
+    of the SAME workload: B = 2 utterances per pass, all host cores of this job."""
     import torch
     from oracle import idccrn_oracle as O
+    from oracle import stock_cpu
     cores = host_cores()
     torch.set_num_threads(cores)
     np_ = O.net_params(True, 32)
@@ -136,13 +224,18 @@ def cpu_baseline(seconds_budget=20.0):
     m = pm.DCCRN_(NFFT, HOP, np_, True, "cpu", WIN, SKIP, "mask", False, None, None)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = O.synth_state_dict(shapes, 51)
+    net = stock_cpu.StockDCCRN(np_, NFFT, HOP, WIN).load_reference_state(sd)
     B = 2
     noisy, clean, _ = make_inputs(B, 123, "cpu")
 
     def one():
-        with torch.no_grad():
-            est, pred, _ = O.dccrn_forward(noisy, sd, np_, True, NFFT, HOP, WIN, SKIP, "mask", False)
-            return O.multiple_recon_loss(pred, O.stft(clean, NFFT, HOP, WIN), clean, est, [0.0, 0.0, 1.0])[0]
+        with torch.set_grad_enabled(train):
+            est, pred = net(noisy, train=train)
+            loss = O.multiple_recon_loss(pred, net.stft(clean), clean, est, [0.0, 0.0, 1.0])[0]
+            if train:
+                net.zero_grad(set_to_none=True)
+                loss.backward()
+            return loss
     one()
     t0 = time.perf_counter()
     n = 0
@@ -152,9 +245,100 @@ def cpu_baseline(seconds_budget=20.0):
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= 24:
             break
+    what = "forward(train=True) + final_ete_loss + backward" if train else "forward + final_ete_loss"
     return {"value": round(B * n / el, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} passes of B={B} 4 s utterances, DCCRN-CL forward + final_ete_loss, torch-CPU oracle "
-                      f"(oracle/idccrn_oracle.py), {cores} threads"}
+            "sample": f"{n} passes of B={B} 4 s utterances, DCCRN-CL {what}, stock torch-CPU modules as the reference "
+                      f"assembles them (oracle/stock_cpu.py), {cores} threads",
+            "vs_reference_note": "build-container cross-check against the imported reference: BASELINE.md section 2"}
+
+
+TRAIN_WORKLOADS = ("dccrn_cl_train", "cvae_train", "nsvae_train", "twophase_train")
+
+
+def kernel_name(cfg_id):
+    if cfg_id == -97:
+        return "void (anonymous namespace)::wgrad_kernel<5, 2, 2, 1, 16>(WgradArgs) + wgrad_unpack_conv_kernel"
+    if cfg_id in (-99, -98):
+        return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
+    if cfg_id > 0:
+        d = str(cfg_id)
+        mode, t = (1 if len(d) == 7 else 0), d[-6:]
+        return f"void cgemm_kernel<{mode}, {t[0]}, {t[1]}, {t[2]}, {t[3]}, {t[4]}, {t[5]}, false, false, true>(CgemmArgs)"
+    if cfg_id <= -100000000:       # idv_cconv_img_config digits <MODE, WM, WN, FO_T, JC_W, MT_W, IMGIN, AD>
+        d = str(-cfg_id - 100000000).rjust(8, "0")
+        return (f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false, {d[5]}, "
+                f"{'true' if d[6] == '1' else 'false'}, {d[7]}>(CgemmArgs)")
+    d = str(-cfg_id - 1000000).rjust(6, "0")
+    return f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false, {d[5]}, false, 2>(CgemmArgs)"
+
+
+def group_launches(entries):
+    out = {}
+    for cfg_id, macs, e0, e1 in entries:
+        g = out.setdefault(cfg_id, [0, 0.0, 0])
+        g[0] += macs
+        g[1] += e0.elapsed_time(e1) * 1e-3
+        g[2] += 1
+    return out
+
+
+def roofline_of(launches, steps, step_seconds, precision, batch, workload):
+    """Roofline block for the dominant contraction kernel of a timed region (HIP-event intervals on the launch stream)."""
+    groups = group_launches(launches)
+    if not groups:
+        return None
+    dom = max(groups, key=lambda k: groups[k][1])
+    macs, secs, n = groups[dom]
+    tot_macs = sum(g[0] for g in groups.values())
+    tot_secs = sum(g[1] for g in groups.values())
+    split = dom < 0 and dom != -97
+    peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    ach = 2 * macs / secs / 1e12
+    traffic, tsrc = None, None
+    tname = "r02_traffic_f32.json" if precision == "fp32" else "r02_traffic_bf16x3.json"
+    tpath = os.path.join(ROOT, "profiles", tname)
+    if os.path.exists(tpath) and batch == DEFAULT_BATCH and workload == "dccrn_cl":
+        tk = json.load(open(tpath))["kernels"].get(kernel_name(dom))
+        if tk:
+            traffic, tsrc = tk["hbm_bytes_per_launch"], "profiles/" + tname
+    r = {
+        "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+        "traffic": traffic,
+        "traffic_note": f"HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from the committed rocprofv3 --pmc passes ({tsrc}, "
+                        "same command and batch); null when the run differs from that command",
+        "peak_note": ("dense bf16 MFMA peak; achieved counts ALGORITHMIC fp32 flops (4 real convs), the kernel executes 3 bf16 "
+                      "MFMA products per algorithmic product" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+        "kernel": kernel_name(dom), "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
+        "algorithmic_gflop_per_launch": round(2 * macs / n / 1e9, 3),
+        "all_conv_launches": {"achieved": round(2 * tot_macs / tot_secs / 1e12, 3),
+                              "frac": round(2 * tot_macs / tot_secs / 1e12 / peak, 4),
+                              "share_of_step_time": round(tot_secs / step_seconds / steps, 4)},
+        "per_kernel": {kernel_name(k): {"tflops": round(2 * v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3)}
+                       for k, v in sorted(groups.items())},
+    }
+    if split:
+        r["executed_bf16_tflops"] = round(3 * ach, 1)
+        r["frac_executed"] = round(3 * ach / peak, 4)
+        r["vs_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 3)
+    return r
+
+
+def timed(step, steps, ops, barrier=None):
+    import torch
+    ops.LAUNCH_LOG = []
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    el = time.perf_counter() - t0
+    launches, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    return el, launches, last
 
 
 def main():
@@ -162,12 +346,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default 64; train workloads 32)")
     ap.add_argument("--workload", default="dccrn_cl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("IDV_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
-                    help="conv contraction arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 record")
+    ap.add_argument("--precision", default=os.environ.get("IDV_PRECISION", "fp32"), choices=["fp32", "bf16x3"],
+                    help="conv contraction arithmetic of the HEADLINE: exact fp32 MFMA (the reference's precision, default), "
+                         "or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
+    train = args.workload in TRAIN_WORKLOADS
+    if args.batch is None:
+        args.batch = 32 if train else DEFAULT_BATCH
 
     import torch
     import torch.distributed as dist
@@ -184,6 +373,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
+        # RCCL before any other GPU work of this process
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("IDV_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
@@ -194,10 +384,10 @@ def main():
 
     ops = importlib.import_module("i-dccrn-vae_amd").ops
     ops.set_precision(args.precision)
-    torch.set_grad_enabled(False)
+    torch.set_grad_enabled(False)                # train workloads enable grad inside their step
     step, utt_per_step, cfg = build_workload(args.workload, args.batch, device, rank)
 
-    log(f"workload {args.workload} B={args.batch} built; warmup {args.warmup}")
+    log(f"workload {args.workload} B={args.batch} precision={args.precision} built; warmup {args.warmup}")
     for w in range(args.warmup):
         step()
         torch.cuda.synchronize()
@@ -207,132 +397,81 @@ def main():
         if world > 1:
             dist.barrier()
 
-    ops.LAUNCH_LOG = []
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launches, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    elapsed, launches, last = timed(step, args.steps, ops, barrier)
     loss_val = float(last)
     log(f"timed {args.steps} steps in {elapsed:.3f} s")
-
-    # Under sub-batch stream overlap a kernel's event interval includes the time its blocks wait behind the other
-    # stream's kernel, so kernel quality (the roofline) is measured in a second, single-stream pass of the same steps;
-    # the overlapped intervals of the timed region are reported beside it.
-    overlapped = None
     n_streams = ops.stream_split(args.batch) if args.workload == "dccrn_cl" else 1
-    if n_streams > 1:
-        overlapped = launches
-        keep, ops.STREAM_SPLIT = ops.STREAM_SPLIT, 1
-        step()
-        torch.cuda.synchronize()
-        ops.LAUNCH_LOG = []
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        serial_elapsed = time.perf_counter() - t1
-        launches, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
-        ops.STREAM_SPLIT = keep
-        log(f"single-stream roofline pass: {args.steps} steps in {serial_elapsed:.3f} s")
-    else:
-        serial_elapsed = elapsed
 
     dt = importlib.import_module("i-dccrn-vae_amd.utils.dist_timing")
     red_dev = device if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
-    value, elapsed = dt.job_throughput(elapsed, float(utt_per_step * args.steps), red_dev)
+    value, elapsed_max = dt.job_throughput(elapsed, float(utt_per_step * args.steps), red_dev)
+    roofline = roofline_of(launches, args.steps, elapsed / args.steps, args.precision, args.batch, args.workload)
+    if roofline is not None and n_streams > 1:
+        roofline["note"] = (f"timed region ran {n_streams} sub-batch streams (IDV_STREAM_SPLIT): event intervals include CU "
+                            "time-slicing with the other stream")
 
-    # dominant kernel: group conv launches by kernel instantiation, HIP-event durations on the launch stream
-    def kernel_name(cfg_id):
-        if cfg_id in (-99, -98):
-            return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
-        if cfg_id > 0:
-            d = str(cfg_id)
-            mode, t = (1 if len(d) == 7 else 0), d[-6:]
-            return f"void cgemm_kernel<{mode}, {t[0]}, {t[1]}, {t[2]}, {t[3]}, {t[4]}, {t[5]}, false, false, true>(CgemmArgs)"
-        if cfg_id <= -100000000:       # idv_cconv_img_config digits <MODE, WM, WN, FO_T, JC_W, MT_W, IMGIN, AD>
-            d = str(-cfg_id - 100000000).rjust(8, "0")
-            return (f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false, {d[5]}, "
-                    f"{'true' if d[6] == '1' else 'false'}, {d[7]}>(CgemmArgs)")
-        d = str(-cfg_id - 1000000).rjust(6, "0")
-        return f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false, {d[5]}, false, 2>(CgemmArgs)"
+    # ---- secondary record: the split-bf16 mode on the same workload (narrower arithmetic than the reference: never `value`)
+    alt = None
+    if (world == 1 and not args.no_alt and args.workload == "dccrn_cl" and args.precision == "fp32"):
+        keep_split = ops.STREAM_SPLIT
+        try:
+            ops.set_precision("bf16x3")
+            ops.STREAM_SPLIT = 1
+            for _ in range(2):
+                step()
+            a_el, a_launch, a_last = timed(step, args.steps, ops)
+            alt = {"dtype": "bf16x3 (split-fp32 operands on the bf16 MFMA: w*x ~ w_hi*x_hi + w_hi*x_lo + w_lo*x_hi, fp32 "
+                            "accumulate; ~16-17 significant bits per operand, waveform 5e-6 from the fp32 reference)",
+                   "value": round(utt_per_step * args.steps / a_el, 3), "unit": "utterances/sec",
+                   "ms_per_step": round(a_el / args.steps * 1e3, 3), "streams": 1, "loss": float(a_last),
+                   "roofline": roofline_of(a_launch, args.steps, a_el / args.steps, "bf16x3", args.batch, args.workload)}
+            # two HIP streams (sub-batch pipelining, opt-in via IDV_STREAM_SPLIT=2): throughput + ONE bit-exactness check of
+            # its output against the one-stream output of the same input
+            pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+            probe = {}
+            orig_forward = pm.DCCRN_.forward
 
-    def group(entries):
-        out = {}
-        for cfg_id, macs, e0, e1 in entries:
-            g = out.setdefault(cfg_id, [0, 0.0, 0])
-            g[0] += macs
-            g[1] += e0.elapsed_time(e1) * 1e-3
-            g[2] += 1
-        return out
-
-    groups = group(launches)
-    roofline = None
-    if groups:
-        dom = max(groups, key=lambda k: groups[k][1])
-        macs, secs, n = groups[dom]
-        tot_macs = sum(g[0] for g in groups.values())
-        tot_secs = sum(g[1] for g in groups.values())
-        split = dom < 0
-        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        ach = 2 * macs / secs / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and args.batch == DEFAULT_BATCH and args.workload == "dccrn_cl":     # single-stream launches
-            tk = json.load(open(tpath))["kernels"].get(kernel_name(dom))
-            if tk:
-                traffic = tk["hbm_bytes_per_launch"]
-        roofline = {
-            "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": traffic,
-            "traffic_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from the committed rocprofv3 --pmc passes "
-                            "(profiles/r01_traffic.json, same command and batch); null when the run differs from that command",
-            "peak_note": ("dense bf16 MFMA peak; achieved counts ALGORITHMIC fp32 flops (4 real convs), the kernel executes 3 bf16 "
-                          "MFMA products per algorithmic product" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
-            "kernel": kernel_name(dom), "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
-            "algorithmic_gflop_per_launch": round(2 * macs / n / 1e9, 3),
-            "all_conv_launches": {"achieved": round(2 * tot_macs / tot_secs / 1e12, 3),
-                                  "frac": round(2 * tot_macs / tot_secs / 1e12 / peak, 4),
-                                  "share_of_step_time": round(tot_secs / serial_elapsed, 4)},
-            "per_kernel": {kernel_name(k): {"tflops": round(2 * v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / args.steps * 1e3, 3)}
-                           for k, v in sorted(groups.items())},
-        }
-        if overlapped is not None:
-            og = group(overlapped)
-            om, osec, on = og.get(dom, (0, 1.0, 1))
-            roofline["measured_in"] = (f"single-stream pass (IDV_STREAM_SPLIT=1) of the same {args.steps} steps, "
-                                       f"{round(serial_elapsed / args.steps * 1e3, 3)} ms/step; `value` is the {n_streams}-stream timed region")
-            roofline["timed_region_overlapped"] = {
-                "streams": n_streams, "launches": on, "avg_launch_ms": round(osec / on * 1e3, 4),
-                "achieved": round(2 * om / osec / 1e12, 3), "frac": round(2 * om / osec / 1e12 / peak, 4),
-                "note": "event intervals on each sub-batch stream; they include CU time-slicing with the other stream"}
-        if split:
-            roofline["clock_note"] = ("committed counters (profiles/r01h: GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES): the conv kernels run "
-                                      "power-limited at 1.65-1.80 GHz and the MFMA pipe is busy 65-78 % of those cycles; `peak` is the "
-                                      "dense bf16 rate at the nominal 2.4 GHz")
-            roofline["executed_bf16_tflops"] = round(3 * ach, 1)
-            roofline["frac_executed"] = round(3 * ach / peak, 4)
-            roofline["vs_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 3)
+            def spy(self, signal, train=True):
+                r = orig_forward(self, signal, train)
+                probe["est"] = r[0]
+                return r
+            pm.DCCRN_.forward = spy
+            try:
+                step()
+                one = probe["est"].clone()
+                ops.STREAM_SPLIT = 2
+                step()
+                b_el, _, _ = timed(step, args.steps, ops)
+                torch.cuda.synchronize()
+                alt["two_stream"] = {"value": round(utt_per_step * args.steps / b_el, 3), "ms_per_step": round(b_el / args.steps * 1e3, 3),
+                                     "streams": ops.stream_split(args.batch)}
+                alt["two_stream_bit_exact"] = bool(torch.equal(one, probe["est"]))
+            finally:
+                pm.DCCRN_.forward = orig_forward
+        finally:
+            ops.STREAM_SPLIT = keep_split
+            ops.set_precision(args.precision)
+        log(f"alt bf16x3: {alt['value']} utt/s, two-stream {alt.get('two_stream')}, bit exact {alt.get('two_stream_bit_exact')}")
 
     if rank == 0:
         out = {
             "metric": METRIC, "value": round(value, 3), "unit": "utterances/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-fp32 operands on bf16 MFMA, fp32 accumulate)", "data": "synthetic (0.1*N(0,1) clean + noise, seeded; random-init weights)",
-            "config": dict(cfg, utterance="4 s @ 16 kHz (64000 samples, 641 frames)", parallelism=f"replicas x{world}",
-                           loss=loss_val),
+            "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-fp32 operands on bf16 MFMA, fp32 accumulate)",
+            "data": "synthetic (0.1*N(0,1) clean + noise, seeded; random-init weights)",
+            "config": dict(cfg, utterance="4 s @ 16 kHz (64000 samples, 641 frames)",
+                           parallelism=(f"data-parallel x{world}: sharded batch, Sync-CBN moment all-reduce, gradient all-reduce (RCCL)"
+                                        if train else f"replicas x{world}"),
+                           streams=n_streams, loss=loss_val),
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "dccrn_cl":
+        if alt is not None:
+            out["alt"] = alt
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("dccrn_cl", "dccrn_cl_train"):
             log("cpu baseline ...")
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(train=train)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void cbn_bwd_finalize_kernel(const double* __r
                                                                int C, float* __restrict__ coef, float* __restrict__ dg_rr,
                                                                float* __restrict__ dg_ri, float* __restrict__ dg_ii,
                                                                float* __restrict__ db_r, float* __restrict__ db_i,
-                                                               float* __restrict__ dslope) {
+                                                               float* __restrict__ dslope, float pscale) {
     __shared__ double shs[256];
     double sl = 0;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -88,11 +88,11 @@ __global__ __launch_bounds__(256) void cbn_bwd_finalize_kernel(const double* __r
         // dZ = sum du (x) (y - mu)
         const double Sr = s[0], Si = s[1];
         const double dZrr = s[2] - mur * Sr, dZri = s[3] - mui * Sr, dZir = s[4] - mur * Si, dZii = s[5] - mui * Si;
-        dg_rr[c] = (float)(dZrr * Wrr + dZri * Wri);
-        dg_ri[c] = (float)(dZrr * Wri + dZri * Wii + dZir * Wrr + dZii * Wri);
-        dg_ii[c] = (float)(dZir * Wri + dZii * Wii);
-        db_r[c] = (float)Sr;
-        db_i[c] = (float)Si;
+        dg_rr[c] = (float)(pscale * (dZrr * Wrr + dZri * Wri));
+        dg_ri[c] = (float)(pscale * (dZrr * Wri + dZri * Wii + dZir * Wrr + dZii * Wri));
+        dg_ii[c] = (float)(pscale * (dZir * Wri + dZii * Wii));
+        db_r[c] = (float)(pscale * Sr);
+        db_i[c] = (float)(pscale * Si);
         const double dWrr = dZrr * grr + dZir * gri;
         const double dWri = dZrr * gri + dZri * grr + dZir * gii + dZii * gri;
         const double dWii = dZri * gri + dZii * gii;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void cbn_bwd_finalize_kernel(const double* __r
     if (threadIdx.x == 0 && dslope) {
         double t = 0;
         for (int i = 0; i < (int)blockDim.x; ++i) t += shs[i];
-        dslope[0] = (float)t;
+        dslope[0] = (float)(pscale * t);
     }
 }
 
@@ -537,12 +537,12 @@ extern "C" int idv_cbn_bwd_reduce(const float* dz, const float* y, const float* 
 extern "C" int idv_cbn_bwd_finalize(const double* sums, double count, const float* moments, const float* gamma_rr,
                                     const float* gamma_ri, const float* gamma_ii, int C, float* coef, float* dgamma_rr,
                                     float* dgamma_ri, float* dgamma_ii, float* dbeta_r, float* dbeta_i, float* dslope,
-                                    void* stream) {
+                                    float param_grad_scale, void* stream) {
     if (!sums || count <= 0 || !moments || !gamma_rr || !gamma_ri || !gamma_ii || !coef || !dgamma_rr || !dgamma_ri ||
         !dgamma_ii || !dbeta_r || !dbeta_i || C <= 0)
         return IDV_EINVAL;
     hipLaunchKernelGGL(cbn_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, count, moments, gamma_rr,
-                       gamma_ri, gamma_ii, C, coef, dgamma_rr, dgamma_ri, dgamma_ii, dbeta_r, dbeta_i, dslope);
+                       gamma_ri, gamma_ii, C, coef, dgamma_rr, dgamma_ri, dgamma_ii, dbeta_r, dbeta_i, dslope, param_grad_scale);
     return idv_launch_status();
 }
 

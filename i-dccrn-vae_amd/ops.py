@@ -284,8 +284,8 @@ LAUNCH_LOG = None
 # Concurrent queues are only safe because the library is built without packed-fp32 VALU code (__graft_entry__.build,
 # -fno-slp-vectorize): on MI355X v_pk_fma_f32 / v_pk_mul_f32 results of one kernel came out wrong in 16-lane slices
 # while an MFMA-saturating kernel of another stream shared its SIMDs.
-STREAM_SPLIT = int(os.environ.get("IDV_STREAM_SPLIT", "2"))
-CONCURRENT = os.environ.get("IDV_CONCURRENT", "1") != "0"      # ops.concurrent really uses several streams
+STREAM_SPLIT = int(os.environ.get("IDV_STREAM_SPLIT", "1"))     # opt-in: 2 = sub-batch pipelining
+CONCURRENT = os.environ.get("IDV_CONCURRENT", "0") != "0"      # opt-in: ops.concurrent really uses several streams
 STREAM_STAGGER = os.environ.get("IDV_STREAM_STAGGER", "1") != "0"   # part k+1 starts when part k reaches its LSTM
 STREAM_STAGGER_BELOW = 1 << 30                   # parts below this size are staggered; measured +6 / +4 / +2 % at B = 64 / 96 / 128
 STREAM_SPLIT_MIN_BATCH = 16                      # per-stream utterances below which launch overhead dominates
@@ -580,6 +580,8 @@ def cbn_train(act: Planar, stats: torch.Tensor, bn, slope, first_call: bool, mom
     moments = torch.empty(5, C, dtype=torch.float32, device=dev)
     fold = torch.empty(C, 6, dtype=torch.float32, device=dev)
     count = float(act.B) * act.F * act.T
+    if BN_SYNC is not None:
+        count = count * BN_SYNC(stats)
     call("idv_cbn_finalize", p(stats), d(count), p(bn.gamma_rr), p(bn.gamma_ri), p(bn.gamma_ii), p(bn.beta_r), p(bn.beta_i),
          i(C), i(1 if first_call else 0), f(momentum), p(bn.running_mean_real), p(bn.running_mean_imag), p(bn.Vrr), p(bn.Vri),
          p(bn.Vii), p(moments), p(fold), stream_ptr())
@@ -710,12 +712,21 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
     adj_transposed = not fwd_transposed
     Fout = 2 * dy.F - 1 if adj_transposed else (dy.F - 1) // 2 + 1
     out = Planar.empty(cout_adj, Fout, dy.B, dy.T, dy.Tp, dy.buf.device)
+    if LAUNCH_LOG is not None:
+        cfg = L.lib().idv_cconv_config(i(1 if adj_transposed else 0), i(dy.C), i(cout_adj), i(dy.F))
+        macs = 4 * dy.C * cout_adj * 10 * dy.B * dy.T * (dy.F if adj_transposed else Fout)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     call("idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(wfrag), p(bias), p(None), out.ptr(), p(None),
          i(1 if adj_transposed else 0), i(0), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(dy.T), stream_ptr())
+    if LAUNCH_LOG is not None:
+        ev1.record()
+        LAUNCH_LOG.append((cfg, macs, ev0, ev1))
     return out
 
 
 _WORK = {}
+WGRAD_CFG = -97          # LAUNCH_LOG id of the conv weight-gradient kernel (wgrad_kernel<5, 2, 2, 1, 16> + its unpack)
 
 
 def _scratch(n: int, device, tag="w") -> torch.Tensor:
@@ -733,8 +744,15 @@ def cconv_wgrad(x: Planar, ci_off: int, dy: Planar, cout: int, cin_total: int, t
     cs, cl = (x.C, cout) if transposed else (cout, x.C)
     n = int(_ll_fn("idv_cconv_wgrad_work_floats")(i(cs), i(cl), i(x.B), i(x.Tp)))
     work = _scratch(n, x.buf.device)
+    if LAUNCH_LOG is not None:
+        macs = 4 * x.C * cout * 10 * x.B * x.T * (x.F if transposed else dy.F)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     call("idv_cconv2d_bwd_weight", x.ptr(), i(x.C), i(ci_off), dy.ptr(), i(cout), i(cin_total), i(1 if transposed else 0),
          i(tshift), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(dy.Jp), p(work), ll(work.numel()), p(dw_re), p(dw_im), stream_ptr())
+    if LAUNCH_LOG is not None:
+        ev1.record()
+        LAUNCH_LOG.append((WGRAD_CFG, macs, ev0, ev1))
 
 
 def cconv_bias_grad(dy: Planar):
@@ -764,13 +782,15 @@ def cbn_bwd(dz: Planar, y: Planar, fold, moments, bn, slope, count: float):
     sums = torch.empty(C, 8, dtype=torch.float64, device=dev)
     call("idv_cbn_bwd_reduce", dz.ptr(), y.ptr(), p(fold), p(slope), i(C), i(y.F), i(y.B), i(y.Tp), i(y.Jp), i(y.T), p(sums),
          stream_ptr())
+    world = 1
     if BN_SYNC is not None:
-        count = count * BN_SYNC(sums)
+        world = BN_SYNC(sums)
+        count = count * world
     coef = torch.empty(C, 12, dtype=torch.float32, device=dev)
     g = [torch.empty(C, dtype=torch.float32, device=dev) for _ in range(5)]
     dslope = torch.zeros(1, dtype=torch.float32, device=dev)
     call("idv_cbn_bwd_finalize", p(sums), d(count), p(moments), p(bn[0]), p(bn[1]), p(bn[2]), i(C), p(coef), p(g[0]), p(g[1]),
-         p(g[2]), p(g[3]), p(g[4]), p(dslope if slope is not None else None), stream_ptr())
+         p(g[2]), p(g[3]), p(g[4]), p(dslope if slope is not None else None), f(1.0 / world), stream_ptr())
     dy = like(y)
     call("idv_cbn_bwd_apply", dz.ptr(), y.ptr(), p(fold), p(coef), p(slope), i(C), i(y.F), i(y.B), i(y.Tp), i(y.Jp), i(y.T),
          dy.ptr(), stream_ptr())

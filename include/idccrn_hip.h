@@ -282,15 +282,16 @@ int idv_planar_rowsum(const float* x, int M, int Jp, int J, int accumulate, floa
  * idv_cbn_apply_prelu_to: out-of-place idv_cbn_apply_prelu (training keeps the conv output y for the backward pass).
  * Backward, three steps: idv_cbn_bwd_reduce (per-channel sums [C][8] doubles of du = dz*PReLU'(u), du (x) y and the PReLU
  * slope term; data-parallel training all-reduces these), idv_cbn_bwd_finalize (moments = the [5][C] output of
- * idv_cbn_finalize, count = B*F*T of the whole batch; -> coef[C][12], d gamma_rr/ri/ii, d beta_r/i, dslope[1]),
- * idv_cbn_bwd_apply (dy = Z^T du + A (y - mu) + c). */
+ * idv_cbn_finalize, count = B*F*T of the whole batch; -> coef[C][12], d gamma_rr/ri/ii, d beta_r/i, dslope[1], each times
+ * param_grad_scale: 1 normally, 1/world when the sums were all-reduced, because the ranks then all hold the gradient of
+ * the SUM of their losses and the gradient all-reduce averages), idv_cbn_bwd_apply (dy = Z^T du + A (y - mu) + c). */
 int idv_cbn_apply_prelu_to(const float* y, const float* fold, const float* prelu_slope, int C, int F, int B, int Tp, int Jp,
                            int t_valid, float* out, void* stream);
 int idv_cbn_bwd_reduce(const float* dz, const float* y, const float* fold, const float* prelu_slope, int C, int F, int B,
                        int Tp, int Jp, int t_valid, double* sums, void* stream);
 int idv_cbn_bwd_finalize(const double* sums, double count, const float* moments, const float* gamma_rr, const float* gamma_ri,
                          const float* gamma_ii, int C, float* coef, float* dgamma_rr, float* dgamma_ri, float* dgamma_ii,
-                         float* dbeta_r, float* dbeta_i, float* dslope, void* stream);
+                         float* dbeta_r, float* dbeta_i, float* dslope, float param_grad_scale, void* stream);
 int idv_cbn_bwd_apply(const float* dz, const float* y, const float* fold, const float* coef, const float* prelu_slope, int C,
                       int F, int B, int Tp, int Jp, int t_valid, float* dy, void* stream);
 

@@ -255,6 +255,93 @@ def test_nsvae_twophase_golden(pm, losses, golden, tag):
     assert r1[4] is None and r1[5] is None and r1[0].shape == z_s.shape
 
 
+def _sub(t, *steps):
+    return t[tuple(slice(None, None, s_) for s_ in steps)]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_vae_full_size_golden(pm, losses, golden, precision):
+    """BASELINE configs 2 / 3 / 5 at their real width (base 32, zdim 128 -> LSTM hidden 384 / 768) on 4 s utterances,
+    against the REAL reference's outputs (tests/golden/make_golden.py vaefull): CVAE encoder + zero-skip decoder + ELBO,
+    NSVAE encoder + repeated-skip mask decoder + phase-2 loss + nsvae KL loss."""
+    ops = pm.ops
+    nl, pl = losses
+    dc, dn = golden("vae_cvae_full_eval"), golden("vae_nsvae_full_eval")
+    base, seed, zdim, ns = int(dc["base"]), int(dc["seed"]), int(dc["zdim"]), int(dc["ns"])
+    tol = WAVE_TOL if precision == "fp32" else 1e-3
+    np_ = O.net_params(True, base)
+    x = T_(dc["x"]).cuda()
+    B, L = x.shape
+    T = 1 + L // HOP
+    rng = lambda sd_, *shape: torch.from_numpy(np.random.default_rng(sd_).standard_normal(shape).astype("float32"))
+    keep = ops.PRECISION
+    try:
+        ops.set_precision(precision)
+        with torch.no_grad():
+            enc = load_synth(pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns), seed)
+            dec = load_synth(pm.pvae_dccrn_decoder_skip_prepare(np_, True, "cuda", ns, zdim, NFFT, HOP, WIN, "real_imag", SKIP), seed + 1)
+            eps = (rng(seed + 300, B, ns, T, zdim).cuda(), rng(seed + 301, B, ns, T, zdim).cuda())
+            z, miu, ls, dl, skiper, C, F, stft_x = enc(x, train=False, eps=eps)
+            assert enc.lstms[0].hidden_size == 384
+            for got, name, st in ((z, "z_sub", (1, 8, 4, 1)), (miu, "miu_sub", (1, 8, 4, 1)), (ls, "ls_sub", (1, 8, 4, 1)),
+                                  (dl, "dl_sub", (1, 8, 4, 1)), (skiper[5], "skip5_sub", (1, 8, 1, 8, 1))):
+                assert relerr(_sub(got, *st).cpu(), T_(dc[name])) < tol, name
+            assert abs(float(z.double().norm()) - float(dc["z_l2"])) < tol * float(dc["z_l2"])
+            recon, predict = dec(stft_x, z, skiper, C, F, train=False)
+            assert tuple(recon.shape) == (B * ns, L)
+            assert relerr(_sub(recon, 1, 16).cpu(), T_(dc["recon_sub"])) < tol
+            assert abs(float(recon.double().norm()) - float(dc["recon_l2"])) < tol * float(dc["recon_l2"])
+            assert relerr(_sub(torch.view_as_real(predict), 1, 8, 16, 1).cpu(), T_(dc["pred_sub"])) < tol
+            xr, sx = x.repeat_interleave(ns, dim=0), stft_x.repeat_interleave(ns, dim=0)
+            loss = pl.complex_standard_vae_loss(torch.ones(1), 1.0, 0.0, 'multiple', 'real_imag', [1.0, 1.0, 0.0], ns)
+            out = loss.cal_loss(xr, recon, sx, predict, miu, ls, dl, z, 5)
+            for a, b in zip([out[0], out[1], out[2], out[4], out[5], out[6]], T_(dc["elbo"])):
+                assert abs(float(a) - float(b)) < 10 * tol * max(1.0, abs(float(b)))
+            # NSVAE encoder (H = 768) + fine-tuned decoder with repeated real skips, mask
+            enc2 = load_synth(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns, 2), seed + 2)
+            dec2 = load_synth(pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, "cuda", ns, zdim, NFFT, HOP, WIN, "mask", True, SKIP, False), seed + 3)
+            assert enc2.lstms[0].hidden_size == 768
+            eps2 = tuple(rng(seed + 310 + k, B, ns, T, zdim).cuda() for k in range(4))
+            r = enc2(x, train=False, eps=eps2)
+            z_s, miu_s, ls_s, dl_s, z_n, miu_n, ls_n, dl_n, skiper2, C, F, stft_x2 = r
+            for got, name in ((z_s, "z_speech_sub"), (z_n, "z_noise_sub"), (miu_s, "miu_speech_sub"), (miu_n, "miu_noise_sub"),
+                              (ls_s, "ls_speech_sub"), (dl_n, "dl_noise_sub")):
+                assert relerr(_sub(got, 1, 8, 4, 1).cpu(), T_(dn[name])) < tol, name
+            recon2, pred2 = dec2(stft_x2, z_s, skiper2, C, F, train=False, pad='sig')
+            assert relerr(_sub(recon2, 1, 16).cpu(), T_(dn["recon_sub"])) < tol
+            assert abs(float(recon2.double().norm()) - float(dn["recon_l2"])) < tol * float(dn["recon_l2"])
+            tl = nl.two_phase_loss([0, 0, 1], 1.0, zdim, 1)
+            got = tl.phase_2_loss(pred2, sx, xr, recon2, None, None, None, None)
+            for a, b in zip(got[:4], T_(dn["phase2"])):
+                assert abs(float(a) - float(b)) < 10 * tol * max(1.0, abs(float(b)))
+            L_ = nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.0, zdim, ns, 2, 'original', 'False', [], 'both')
+            o2 = L_.final_nsvae_loss(miu, miu, miu_s, miu_n, ls, ls, ls_s, ls_n, dl, dl, dl_s, dl_n, z_s, z_n, None, None, None)
+            for a, b in zip(o2[:4], T_(dn["nsvae"])):
+                assert abs(float(a) - float(b)) < 10 * tol * max(1.0, abs(float(b)))
+    finally:
+        ops.set_precision(keep)
+
+
+def test_old_module_dccrn_forward(golden):
+    """model/module.py DCCRN_ (the older non-causal wrapper, forward(signal, train) -> waveform only) runs on the GPU and
+    equals the pvae_module DCCRN_ it wraps (it was only ever constructed on the CPU)."""
+    import importlib
+    mod = importlib.import_module("i-dccrn-vae_amd.model.module")
+    pm_ = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    np_ = O.net_params(False, 4)
+    m = mod.DCCRN_(NFFT, HOP, np_, "cuda", WIN)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = O.synth_state_dict(shapes, 23)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    x = torch.randn(2, 1600, generator=torch.Generator().manual_seed(2)) * 0.1
+    with torch.no_grad():
+        y = m(x.cuda(), train=False)
+    sd2 = {("std_DCCRN." + k[6:] if k.startswith("DCCRN.") else k): v for k, v in sd.items()}
+    want, _, _ = O.dccrn_forward(x, sd2, np_, False, NFFT, HOP, WIN, SKIP, "mask", False)
+    assert y.shape == want.shape and relerr(y.cpu(), want) < WAVE_TOL
+
+
 def test_nsvae_loss_from_encoders(pm, losses):
     """config 3 call sequence (train_nsvae.py:487-544): two frozen skip_prepare encoders + the twophase encoder,
     then standard_nsvae_loss_true_kl.final_nsvae_loss - against the oracle on the same latents."""

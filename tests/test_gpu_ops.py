@@ -227,6 +227,37 @@ def test_clstm(ops, golden, H, I, T, B):
     assert float(out.planes()[..., 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("H,I,T,B", [(384, 1280, 641, 2), (768, 1280, 641, 3), (768, 1280, 40, 18)])
+def test_clstm_vae_sizes(ops, precision, H, I, T, B):
+    """The hidden sizes the VAE encoders use (3*zdim = 384, 6*zdim = 768 at zdim 128; BASELINE configs 2-5) at the real
+    input width and a full 4 s sequence, against the oracle in float64: the per-step recurrent kernel, its > 64 KB
+    dynamic-LDS branch (H = 768) and the planar layer-1 projection."""
+    g = torch.Generator().manual_seed(H + T)
+    x = torch.randn(T, B, I, 2, generator=g) * 0.5
+    names = [f"lstm_{s}.{w}_l{l}" for s in ("re", "im") for l in (0, 1) for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    sd = {}
+    for n in names:
+        l = int(n[-1])
+        shape = (4 * H, I if l == 0 else H) if "weight_ih" in n else ((4 * H, H) if "weight_hh" in n else (4 * H,))
+        sd[n] = O.synth_tensor(n, shape, 91) * (2.0 if "weight" in n else 1.0)
+    want = O.complex_lstm(x.double(), {k: v.double() for k, v in sd.items()}, "", 2)
+    xp = ops.Planar.from_tensor5(x.permute(1, 2, 0, 3).unsqueeze(2).cuda())
+    get = lambda n: sd[n].cuda()
+    keep = ops.PRECISION
+    try:
+        ops.set_precision(precision)
+        p0 = ops.pack_lstm(get, H, I, 0, "cuda")
+        p1 = ops.pack_lstm(get, H, H, 1, "cuda")
+        out = ops.clstm(xp, p0, p1, H)
+        got = out.channel_slice(0, H).cpu().permute(1, 0, 2, 3)
+    finally:
+        ops.set_precision(keep)
+    assert torch.isfinite(got).all()
+    assert relerr(got, want) < (TOL if precision == "fp32" else 2e-4)
+    assert float(out.planes()[..., 0].abs().max()) == 0.0
+
+
 def test_cdense_golden(ops, golden):
     d = golden("op_cdense")
     x, want, seed = T_(d["x"]), T_(d["y"]), int(d["seed"])              # x: [21,16,2]

@@ -155,3 +155,52 @@ def test_vae_models(golden):
     rec2, _ = O.vae_decoder_forward(oe2["stft_x"], oe2["z_speech"], oe2["skiper"], oe2["C"], oe2["F"], sd_d2, np_, True, ns,
                                     NFFT, HOP, WIN, "mask", SKIP, "sig", True, False)
     assert relerr(rec2, T_(d2["recon"])) < 1e-4
+
+
+# ----------------------------------------------------------------------------- oracle autograd vs the reference's gradients
+def _summ(t, limit=16384, cap=8192):
+    t = t.detach().reshape(-1)
+    return t if t.numel() <= limit else t[::-(-t.numel() // cap)]
+
+
+def test_oracle_backward_is_pinned_by_reference_gradients(golden):
+    """torch.autograd through the oracle's DCCRN forward + loss reproduces the REAL reference's parameter and input
+    gradients (tests/golden/grad_dccrn_mini.npz, written by make_golden.py `grads`): the GPU gradient tests that compare
+    against oracle autograd therefore compare against the reference."""
+    d = golden("grad_dccrn_mini")
+    base, seed = int(d["base"]), int(d["seed"])
+    np_ = O.net_params(True, base)
+    shapes = {}
+    for k in d.files:
+        if k.startswith("g:"):
+            shapes[k[2:]] = None
+    x = torch.from_numpy(d["x"]).clone().requires_grad_(True)
+    clean_ref = torch.from_numpy(d["clean_ref"])
+    w = [float(v) for v in d["weights"]]
+    # rebuild the full state_dict the fixture was generated with (names + shapes come from this repository's module)
+    import importlib
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    m = pm.DCCRN_(NFFT, HOP, np_, True, "cpu", WIN, SKIP, "mask", False, None, None)
+    sd = O.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
+    est, pred, _ = O.dccrn_forward(x, leaves, np_, True, NFFT, HOP, WIN, SKIP, "mask", True, O.BNState())
+    loss = O.multiple_recon_loss(pred, O.stft(clean_ref, NFFT, HOP, WIN), clean_ref, est, w)
+    loss[0].backward()
+    assert relerr(est.detach(), torch.from_numpy(d["est"])) < 1e-4
+    assert relerr(x.grad, torch.from_numpy(d["gx"])) < 1e-3
+    checked = 0
+    for k in d.files:
+        if not k.startswith("g:"):
+            continue
+        name = k[2:]
+        want, wn = torch.from_numpy(d[k]).double(), float(d["n:" + name])
+        g = leaves[name].grad
+        assert g is not None, name
+        sib = "n:" + name[:-4] + "weight"
+        if name.endswith(".bias") and sib in d.files and wn < 1e-4 * float(d[sib]):
+            continue                                 # true-zero gradients (bias in front of a batch norm): rounding noise
+        got = _summ(g).double()
+        scale = max(wn * (want.numel() / g.numel()) ** 0.5, 1e-12)
+        assert float((got - want).norm()) / scale < 2e-3, name
+        checked += 1
+    assert checked > 100
