@@ -396,6 +396,34 @@ class PlanarToComplexFn(torch.autograd.Function):
         return None, _fit(g, buf)
 
 
+class RepeatBatchFn(torch.autograd.Function):
+    """skip.repeat over num_samples (pvae_module.py:2563-2567) as a materialised planar buffer; backward sums the copies."""
+
+    @staticmethod
+    def forward(ctx, geom, n, buf):
+        out = ops.repeat_batch(_mk(buf, geom), n)
+        ctx.geom, ctx.n, ctx.ogeom = geom, n, _geom(out)
+        ctx.save_for_backward(buf)
+        return out.buf
+
+    @staticmethod
+    def backward(ctx, dobuf):
+        (buf,) = ctx.saved_tensors
+        x = _mk(buf, ctx.geom)
+        do = _mk(dobuf.contiguous(), ctx.ogeom)
+        dx = ops.like(x)
+        call("idv_repeat_batch_bwd", do.ptr(), i(ctx.n), i(2 * x.C * x.F), i(x.B), i(x.Tp), i(do.Jp), i(x.Jp), dx.ptr(),
+             stream_ptr())
+        return None, None, _fit(dx, buf)
+
+
+def repeat_batch(x: Planar, n: int) -> Planar:
+    if grad_mode(x.buf):
+        obuf = RepeatBatchFn.apply(_geom(x), n, x.buf)
+        return Planar(obuf, x.C, x.F, x.B * n, x.T, x.Tp, Planar.jp_for(x.B * n, x.Tp))
+    return ops.repeat_batch(x, n)
+
+
 # ----------------------------------------------------------------------------- reparameterisation
 class ReparamFn(torch.autograd.Function):
     @staticmethod

@@ -491,6 +491,20 @@ __global__ void miu_dist_bwd_kernel(LatRef q1, LatRef q2, int zdim, int B, int T
     }
 }
 
+// adjoint of the batch repeat of the skip connections (pvae_module.py:2563-2567, x.repeat over num_samples):
+//   dx[row][b*Tp + tp] = sum_{s < n} drep[row][(b*n + s)*Tp + tp]
+__global__ void repeat_sum_kernel(const float* __restrict__ drep, int n, int B, int Tp, int Jp_rep, int Jp,
+                                  float* __restrict__ dx) {
+    const int row = blockIdx.y;
+    const int J = B * Tp;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < J; j += gridDim.x * blockDim.x) {
+        const int b = j / Tp, tp = j - b * Tp;
+        float acc = 0.f;
+        for (int s = 0; s < n; ++s) acc += drep[(size_t)row * Jp_rep + (size_t)(b * n + s) * Tp + tp];
+        dx[(size_t)row * Jp + j] = acc;
+    }
+}
+
 // out[m] (+)= sum_{j < J} x[m][j]   (bias gradients of the point-wise contractions)
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, int Jp, int J, int accumulate,
                                                      float* __restrict__ out) {
@@ -645,6 +659,15 @@ extern "C" int idv_miu_dist_bwd(const float* q1, int H1, int Jp1, int off1, cons
     LatRef a{q1, H1, Jp1, off1, 0, 0}, b{q2, H2, Jp2, off2, 0, 0};
     hipLaunchKernelGGL(miu_dist_bwd_kernel, dim3(grid_for(2LL * zdim * B * T)), dim3(256), 0, (hipStream_t)stream, a, b, zdim, B,
                        T, Tp, grad_out, loss_value, dq1, dq2);
+    return idv_launch_status();
+}
+
+extern "C" int idv_repeat_batch_bwd(const float* drep, int n, int rows, int B, int Tp, int Jp_rep, int Jp, float* dx,
+                                    void* stream) {
+    if (!drep || !dx || n < 1 || rows <= 0 || B <= 0 || Tp <= 0 || Jp < B * Tp || Jp_rep < B * n * Tp) return IDV_EINVAL;
+    int gx = (B * Tp + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(repeat_sum_kernel, dim3(gx, rows), dim3(256), 0, (hipStream_t)stream, drep, n, B, Tp, Jp_rep, Jp, dx);
     return idv_launch_status();
 }
 

@@ -10,12 +10,12 @@
 //   G[kf][kt][sp][lp] = sum_{fs, j} S[sp][fs][j] * L[lp][2*fs + kf - 2][j + kt + dt0]
 //
 // i.e. a GEMM with M = S planes, N = L planes x 10 taps and K = Fs x J (millions) -> split-K: every workgroup
-// owns one (128 S planes x 64 L planes x 10 taps) output tile over a contiguous range of column tiles and
+// owns one (128 S planes x 32 L planes x 10 taps) output tile over a contiguous range of column tiles and
 // writes its partial tile to a workspace; the unpack kernel sums the partials in a fixed order (deterministic,
 // no atomics) and folds the four real products of a complex pair into (dW_re, dW_im).
 // MFMA: v_mfma_f32_32x32x2_f32 (exact fp32).  As in the forward kernel the two k of one instruction are two
 // adjacent columns: lanes 0-31 read LDS column c, lanes 32-63 column c+1, so the time tap is a free column
-// offset and all LDS reads are conflict free (row pitch 34 words, plane pitch 170 words).
+// offset and all LDS reads are conflict free (odd row and plane pitches against the 32 banks of ds_read_b32).
 #include "common.hpp"
 #include "../../include/idccrn_hip.h"
 
@@ -33,15 +33,21 @@ struct WgradArgs {
     int jt_per_split;
 };
 
-// WG_JT columns per step; LDS row pitch WG_JT + 2 words (pitch/2 odd -> 64 distinct banks for (plane, half))
-// KF x KT taps; MT_W / NT_W 32-plane tiles per wave along S / L; 2 x 2 waves
-template <int KF, int KT, int MT_W, int NT_W, int WG_JT>
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
-    constexpr int WG_PS = WG_JT + 2;
+// WG_JT columns per step; LDS row pitch WG_JT + 3 words: odd, so the 32 planes one 32-lane half reads with ds_read_b32
+// (bank = word address % 32, lanes l and l+32 never conflict) land on 32 distinct banks, for the S tile (plane pitch =
+// row pitch) and for the L tile (plane pitch = KF * row pitch, KF odd)
+// KF x KT taps; MT_W / NT_W 32-plane tiles per wave along S / L; WM x WN waves (4 in all).
+// The accumulators (MT_W * NT_W * KF * KT tiles of 16 registers) must fit the 256 AGPRs: beyond that hipcc keeps the
+// excess in VGPRs and swaps them through a[0:15] around every MFMA (32 v_accvgpr moves + 16 wait states each).  The conv
+// instantiation therefore holds 10 tiles per wave (one 32 x 32 plane tile x 10 taps) and runs two workgroups per CU.
+template <int KF, int KT, int MT_W, int NT_W, int WM, int WN, int WG_JT, int OCC>
+__global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
+    static_assert(WM * WN == 4 && MT_W * NT_W * KF * KT <= 16, "4 waves; accumulators within the AGPR file");
+    constexpr int WG_PS = WG_JT + 3;
     constexpr int Q4 = WG_JT / 4;                             // float4 slots per row
-    constexpr int KUNR = (KF * KT > 1) ? 1 : 4;               // 20 accumulator tiles leave no room to unroll the k loop
-    static_assert(((WG_PS / 2) & 1) == 1 && ((KF * WG_PS / 2) & 1) == 1, "LDS pitches must be 2 * odd");
-    constexpr int MS = 2 * MT_W * 32, ML = 2 * NT_W * 32;
+    constexpr int KUNR = (KF * KT > 1) ? 2 : 4;
+    static_assert((WG_PS & 1) == 1 && ((KF * WG_PS) & 1) == 1, "LDS pitches must be odd");
+    constexpr int MS = WM * MT_W * 32, ML = WN * NT_W * 32;
     constexpr int TAPS = KF * KT;
     constexpr int S_SLOTS = MS * (WG_JT / 4);                 // float4 slots of the S tile
     constexpr int L_ROWS = ML * KF;
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
     const int split = blockIdx.x, ts = blockIdx.y, tl = blockIdx.z;
     const int sp0 = ts * MS, lp0 = tl * ML;
@@ -75,6 +81,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
     f32x4 sreg[NS4], lreg[NL4];
     float hreg[NH];
 
+    // Staging is branch-free: every slot loads unconditionally (invalid slots read element 0 of their tensor, which is
+    // mapped memory) and the validity masks are applied when the registers are written to LDS one step later -- a
+    // conditional load followed by its mask makes the compiler wait for each load in turn (vmcnt(0) after every one).
     auto load_step = [&](int step) {
         const int jt = jt0 + step / a.Fs, fs = step - (step / a.Fs) * a.Fs;
         const int j0 = jt * WG_JT;
@@ -83,14 +92,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
             const int e = tid + i * 256;
             const int row = e / Q4, q = e - row * Q4;
             const int sp = sp0 + row, j = j0 + 4 * q;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < S_SLOTS && sp < a.Sp && j < a.J) {
-                v = *(const f32x4*)(a.S + ((size_t)sp * a.Fs + fs) * a.JpS + j);
-#pragma unroll
-                for (int c = 1; c < 4; ++c)
-                    if (j + c >= a.J) v[c] = 0.f;
-            }
-            sreg[i] = v;
+            const bool ok = (e < S_SLOTS) && (sp < a.Sp) && (j < a.J);
+            const size_t off = ok ? ((size_t)sp * a.Fs + fs) * a.JpS + j : 0;
+            sreg[i] = *(const f32x4*)(a.S + off);
         }
 #pragma unroll
         for (int i = 0; i < NL4; ++i) {
@@ -98,14 +102,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
             const int row = e / Q4, q = e - row * Q4;
             const int pl = row / KF, kf = row - pl * KF;
             const int lp = lp0 + pl, fl = (KF == 1) ? fs : 2 * fs + kf - 2, j = j0 + 4 * q;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < L_SLOTS && lp < a.Lp && fl >= 0 && fl < a.Fl && j < a.J) {
-                v = *(const f32x4*)(a.L + ((size_t)lp * a.Fl + fl) * a.JpL + j);
-#pragma unroll
-                for (int c = 1; c < 4; ++c)
-                    if (j + c >= a.J) v[c] = 0.f;
-            }
-            lreg[i] = v;
+            const bool ok = (e < L_SLOTS) && (lp < a.Lp) && (fl >= 0) && (fl < a.Fl) && (j < a.J);
+            const size_t off = ok ? ((size_t)lp * a.Fl + fl) * a.JpL + j : 0;
+            lreg[i] = *(const f32x4*)(a.L + off);
         }
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
@@ -114,62 +113,90 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
             const int pl = row / KF, kf = row - pl * KF;
             const int lp = lp0 + pl, fl = (KF == 1) ? fs : 2 * fs + kf - 2;
             const int j = side ? j0 + WG_JT : j0 - 1;
-            float v = 0.f;
-            if (e < L_ROWS * 2 && lp < a.Lp && fl >= 0 && fl < a.Fl && j >= 0 && j < a.J)
-                v = a.L[((size_t)lp * a.Fl + fl) * a.JpL + j];
-            hreg[i] = v;
+            const bool ok = (e < L_ROWS * 2) && (lp < a.Lp) && (fl >= 0) && (fl < a.Fl) && (j >= 0) && (j < a.J);
+            const size_t off = ok ? ((size_t)lp * a.Fl + fl) * a.JpL + j : 0;
+            hreg[i] = a.L[off];
         }
     };
-    auto store_step = [&]() {
+    auto store_step = [&](int step) {
+        const int jt = jt0 + step / a.Fs, fs = step - (step / a.Fs) * a.Fs;
+        const int j0 = jt * WG_JT;
 #pragma unroll
         for (int i = 0; i < NS4; ++i) {
             const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int sp = sp0 + row, j = j0 + 4 * q;
+            const bool ok = (sp < a.Sp);
             if (e < S_SLOTS) {
-                float* d = Ssm + (e / Q4) * WG_PS + 4 * (e % Q4);
+                float* d = Ssm + row * WG_PS + 4 * q;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) d[c] = sreg[i][c];
+                for (int c = 0; c < 4; ++c) d[c] = (ok && j + c < a.J) ? sreg[i][c] : 0.f;
             }
         }
 #pragma unroll
         for (int i = 0; i < NL4; ++i) {
             const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int pl = row / KF, kf = row - pl * KF;
+            const int lp = lp0 + pl, fl = (KF == 1) ? fs : 2 * fs + kf - 2, j = j0 + 4 * q;
+            const bool ok = (lp < a.Lp) && (fl >= 0) && (fl < a.Fl);
             if (e < L_SLOTS) {
-                float* d = Lsm + (e / Q4) * WG_PS + 1 + 4 * (e % Q4);      // LDS column c = j - j0 + 1
+                float* d = Lsm + row * WG_PS + 1 + 4 * q;                // LDS column c = j - j0 + 1
 #pragma unroll
-                for (int c = 0; c < 4; ++c) d[c] = lreg[i][c];
+                for (int c = 0; c < 4; ++c) d[c] = (ok && j + c < a.J) ? lreg[i][c] : 0.f;
             }
         }
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
             const int e = tid + i * 256;
-            if (e < L_ROWS * 2) Lsm[(e >> 1) * WG_PS + ((e & 1) ? WG_JT + 1 : 0)] = hreg[i];
+            const int row = e >> 1, side = e & 1;
+            const int pl = row / KF, kf = row - pl * KF;
+            const int lp = lp0 + pl, fl = (KF == 1) ? fs : 2 * fs + kf - 2;
+            const int j = side ? j0 + WG_JT : j0 - 1;
+            const bool ok = (lp < a.Lp) && (fl >= 0) && (fl < a.Fl) && (j >= 0) && (j < a.J);
+            if (e < L_ROWS * 2) Lsm[row * WG_PS + (side ? WG_JT + 1 : 0)] = ok ? hreg[i] : 0.f;
         }
     };
 
     if (nsteps > 0) load_step(0);
     for (int step = 0; step < nsteps; ++step) {
-        store_step();
+        store_step(step);
         __syncthreads();
         if (step + 1 < nsteps) load_step(step + 1);      // global loads fly under this step's MFMAs
         const float* As = Ssm + (wm * MT_W * 32 + l31) * WG_PS + half;
         const float* Bs = Lsm + ((wn * NT_W * 32 + l31) * KF) * WG_PS + half + 1 + a.dt0;
-#pragma unroll KUNR
-        for (int ks = 0; ks < WG_JT / 2; ++ks) {
+        // LDS operands one k-step ahead of the MFMAs: the ds_read latency hides behind the previous k-step's MFMAs
+        float av[MT_W], bv[NT_W][TAPS], an[MT_W], bn[NT_W][TAPS];
+        auto lds_load = [&](int ks, float (&ao)[MT_W], float (&bo)[NT_W][TAPS]) {
             const int col = 2 * ks;
-            float av[MT_W];
 #pragma unroll
-            for (int i = 0; i < MT_W; ++i) av[i] = As[i * 32 * WG_PS + col];
+            for (int i = 0; i < MT_W; ++i) ao[i] = As[i * 32 * WG_PS + col];
 #pragma unroll
             for (int n = 0; n < NT_W; ++n)
 #pragma unroll
                 for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) {
-                        const float bv = Bs[(n * 32 * KF + kf) * WG_PS + col + kt];
+                    for (int kt = 0; kt < KT; ++kt) bo[n][kf * KT + kt] = Bs[(n * 32 * KF + kf) * WG_PS + col + kt];
+        };
+        lds_load(0, av, bv);
+#pragma unroll KUNR
+        for (int ks = 0; ks < WG_JT / 2; ++ks) {
+            lds_load(ks + 1 < WG_JT / 2 ? ks + 1 : ks, an, bn);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int i = 0; i < MT_W; ++i)
-                            acc[i][n][kf * KT + kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][n][kf * KT + kt], 0, 0, 0);
-                    }
+            for (int n = 0; n < NT_W; ++n)
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int i = 0; i < MT_W; ++i)
+                        acc[i][n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[n][t], acc[i][n][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT_W; ++i) av[i] = an[i];
+#pragma unroll
+            for (int n = 0; n < NT_W; ++n)
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) bv[n][t] = bn[n][t];
         }
         __syncthreads();
     }
@@ -196,16 +223,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
 __global__ void wgrad_unpack_conv_kernel(const float* __restrict__ part, int nsplit, int SpPad, int LpPad, int Cout, int Cx,
                                          int Cin_total, int ci_off, int transposed, float* __restrict__ dw_re,
                                          float* __restrict__ dw_im) {
-    const long long n = (long long)Cout * Cx * 10;
+    // thread order (l channel fastest, then s channel, then tap): the partial reads of a wave are contiguous along l
+    const int Cs = transposed ? Cx : Cout, Cl = transposed ? Cout : Cx;
+    const long long n = (long long)Cs * Cl * 10;
+    const size_t plane = (size_t)SpPad * LpPad;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
-        const int tap = (int)(idx % 10);
-        const int cil = (int)((idx / 10) % Cx);
-        const int co = (int)(idx / (10LL * Cx));
-        int s_re, s_im, l_re, l_im;
-        if (!transposed) { s_re = co; s_im = Cout + co; l_re = cil; l_im = Cx + cil; }
-        else             { s_re = cil; s_im = Cx + cil; l_re = co; l_im = Cout + co; }
+        const int lc = (int)(idx % Cl);
+        const int sc = (int)((idx / Cl) % Cs);
+        const int tap = (int)(idx / ((long long)Cl * Cs));
+        const int s_re = sc, s_im = Cs + sc, l_re = lc, l_im = Cl + lc;
         double rr = 0, ii = 0, ri = 0, ir = 0;      // G[s_re][l_re], G[s_im][l_im], G[s_re][l_im], G[s_im][l_re]
-        const size_t plane = (size_t)SpPad * LpPad;
         for (int sidx = 0; sidx < nsplit; ++sidx) {
             const float* P = part + ((size_t)sidx * 10 + tap) * plane;
             rr += P[(size_t)s_re * LpPad + l_re];
@@ -214,9 +241,10 @@ __global__ void wgrad_unpack_conv_kernel(const float* __restrict__ part, int nsp
             ir += P[(size_t)s_im * LpPad + l_re];
         }
         // y_r = Wr x_r - Wi x_i, y_i = Wi x_r + Wr x_i  ->  dWr = dy_r x_r + dy_i x_i,  dWi = -dy_r x_i + dy_i x_r
+        // conv: S = dy, L = x;  transposed conv: S = x, L = dy
         const double dwr = rr + ii;
         const double dwi = transposed ? (ri - ir) : (ir - ri);
-        const int ci = ci_off + cil;
+        const int co = transposed ? lc : sc, ci = ci_off + (transposed ? sc : lc);
         const size_t o = transposed ? (((size_t)ci * Cout + co) * 10 + tap) : (((size_t)co * Cin_total + ci) * 10 + tap);
         dw_re[o] = (float)dwr;
         dw_im[o] = (float)dwi;
@@ -252,6 +280,7 @@ __global__ void cconv_bias_grad_kernel(const double* __restrict__ stats, int Cou
 }
 
 constexpr int CONV_JT = 16, PW_JT = 32;
+constexpr int CONV_MS = 128, CONV_ML = 32;      // wgrad_kernel<5, 2, 1, 1, 4, 1, ...>: 4 x 1 waves of one 32 x 32 tile x 10 taps
 
 struct Plan { int tilesS, tilesL, nsplit, jtiles, jt_per_split, SpPad, LpPad; };
 
@@ -262,7 +291,7 @@ inline Plan make_plan(int Sp, int Lp, int J, int MS, int ML, int JT) {
     p.SpPad = p.tilesS * MS;
     p.LpPad = p.tilesL * ML;
     p.jtiles = (J + JT - 1) / JT;
-    int want = (1024 + p.tilesS * p.tilesL - 1) / (p.tilesS * p.tilesL);
+    int want = (2048 + p.tilesS * p.tilesL - 1) / (p.tilesS * p.tilesL);
     if (want < 1) want = 1;
     if (want > p.jtiles) want = p.jtiles;
     p.jt_per_split = (p.jtiles + want - 1) / want;
@@ -281,7 +310,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" long long idv_cconv_wgrad_work_floats(int Cs, int Cl, int B, int Tp) {
     if (Cs <= 0 || Cl <= 0 || B <= 0 || Tp <= 0) return -1;
-    const Plan p = make_plan(2 * Cs, 2 * Cl, B * Tp, 128, 64, CONV_JT);
+    const Plan p = make_plan(2 * Cs, 2 * Cl, B * Tp, CONV_MS, CONV_ML, CONV_JT);
     return (long long)p.nsplit * 10 * p.SpPad * p.LpPad;
 }
 
@@ -307,11 +336,11 @@ extern "C" int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const 
         a.dt0 = 0;
     }
     a.J = B * Tp;
-    const Plan p = make_plan(a.Sp, a.Lp, a.J, 128, 64, CONV_JT);
+    const Plan p = make_plan(a.Sp, a.Lp, a.J, CONV_MS, CONV_ML, CONV_JT);
     if ((long long)p.nsplit * 10 * p.SpPad * p.LpPad > work_floats) return IDV_EINVAL;
     a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles; a.jt_per_split = p.jt_per_split;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((wgrad_kernel<5, 2, 2, 1, CONV_JT>), dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 4, 1, CONV_JT, 2>), dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_unpack_conv_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work, p.nsplit,
                        p.SpPad, p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
     return idv_launch_status();
@@ -344,7 +373,7 @@ extern "C" int idv_pw_bwd_weight(const float* dout, int M, int Jp_d, const float
     if ((long long)p.nsplit * p.SpPad * p.LpPad > work_floats) return IDV_EINVAL;
     a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles; a.jt_per_split = p.jt_per_split;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((wgrad_kernel<1, 1, 2, 2, PW_JT>), dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((wgrad_kernel<1, 1, 2, 2, 2, 2, PW_JT, 1>), dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_unpack_plain_kernel, dim3(grid_for((long long)M * K)), dim3(256), 0, st, work, p.nsplit, p.SpPad,
                        p.LpPad, M, K, ldw, rowmap, H, accumulate, dw);
     return idv_launch_status();

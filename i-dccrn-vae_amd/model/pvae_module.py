@@ -98,9 +98,7 @@ class _Block(nn.Module):
                 raise RuntimeError("split images are an eval-mode format")
             div = kw.get("skip_div", 1)
             if skip is not None and div > 1:
-                if skip.buf.requires_grad:
-                    raise NotImplementedError("gradient through repeated (num_samples) skip connections")
-                skip = ops.repeat_batch(skip, div)
+                skip = AG.repeat_batch(skip, div)
             return AG.conv_block(conv, self.bn, self.prelu.weight, x, skip, kw.get("zero_skip", False))
         if train:
             if kw.get("want", "planar") != "planar":
@@ -149,7 +147,7 @@ class Decoder(_Block):
         if not self.if_bn:
             if AG.grad_mode(x.buf, skip.buf if skip is not None else None, *self.transconv.parameters()):
                 if skip is not None and skip_div > 1:
-                    skip = ops.repeat_batch(skip, skip_div)
+                    skip = AG.repeat_batch(skip, skip_div)
                 return AG.conv_block(self.transconv, None, None, x, skip, zero_skip)
             return self.transconv.forward_planar(x, **kw)
         return self._run(self.transconv, x, train, **kw)
@@ -327,6 +325,10 @@ class DCCRN_(nn.Module):
         # Eval is per-utterance independent (folded BN): run sub-batches on separate HIP streams so one sub-batch's
         # 16-CU LSTM recurrence and kernel tails overlap the other's conv GEMMs.  Train mode needs whole-batch
         # CBN statistics and stays on one stream.
+        if not train and torch.is_grad_enabled():
+            # eval mode builds no graph: the folded-BN kernels have no backward (module docstring)
+            with torch.no_grad():
+                return self.forward(signal, False)
         n = 1 if train else ops.stream_split(signal.shape[0])
         if n == 1:
             return self._forward_one(signal, train)
@@ -437,6 +439,9 @@ class pvae_dccrn_encoder_skip_prepare(_VAEEncoderBase):
         self._setup(net_params, causal, device, zdim, n_fft, hop_len, win_length, num_samples, 1)
 
     def forward(self, x, train=True, eps=None):
+        if not train and torch.is_grad_enabled():
+            with torch.no_grad():                                    # eval mode builds no graph
+                return self.forward(x, False, eps)
         lat, skiper, C, F, stft_x = self._encode(x, train)
         z = self.zdim
         return (self._sample(lat, 0, eps), _lstm_out_view(lat, 0, z), _lstm_out_view(lat, z, 2 * z),
@@ -456,6 +461,9 @@ class nsvae_pvae_dccrn_encoder_twophase(_VAEEncoderBase):
         self._setup(net_params, causal, device, zdim, n_fft, hop_len, win_length, num_samples, latent_num)
 
     def forward(self, x, train=True, eps=None):
+        if not train and torch.is_grad_enabled():
+            with torch.no_grad():                                    # eval mode builds no graph
+                return self.forward(x, False, eps)
         lat, skiper, C, F, stft_x = self._encode(x, train)
         z = self.zdim
         out = []
@@ -485,6 +493,9 @@ class _VAEDecoderBase(nn.Module):
         self.istft = ISTFT(n_fft, hop_len, win_length=win_length, device=device)
 
     def _decode(self, stft_x, z, skiper, C, F, train, pad):
+        if not train and torch.is_grad_enabled():
+            with torch.no_grad():                                    # eval mode builds no graph
+                return self._decode(stft_x, z, skiper, C, F, False, pad)
         zp = getattr(z, "_idv", None)
         if zp is None:
             _need_cuda(z)

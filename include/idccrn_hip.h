@@ -300,6 +300,9 @@ int idv_cbn_bwd_apply(const float* dz, const float* y, const float* fold, const 
  * input spectrum, needed when the waveform itself requires grad. */
 int idv_mask_apply_bwd(const float* mask, const float* X, int x_div, int JpX, const float* dpred, const float* dpred_c, int F,
                        int B, int T, int Tp, int Jp, float* dmask, float* dX, void* stream);
+/* Adjoint of repeating every utterance of a planar activation n times in a row (the skip connections of the fine-tuned
+ * decoder, pvae_module.py:2563-2567): dx[row][b*Tp+tp] = sum_s drep[row][(b*n+s)*Tp+tp], rows = 2*C*F planar rows. */
+int idv_repeat_batch_bwd(const float* drep, int n, int rows, int B, int Tp, int Jp_rep, int Jp, float* dx, void* stream);
 /* interleaved [B][F][T][2] -> planar [2][F][Jp] (adjoint of idv_planar_to_complex; also packs a caller's complex tensor). */
 int idv_complex_to_planar(const float* in_c, float* act, int F, int B, int T, int Tp, int Jp, void* stream);
 /* idv_istft_ola backward (pvae_module.py:38-42): dy[B][hop*(T-1)] -> dframes[win][Jp]; the inverse-DFT adjoint is idv_pw_gemm

@@ -483,3 +483,45 @@ def test_eval_after_train_uses_updated_running_stats(pm, ops):
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     want2, _, _ = O.dccrn_forward(x1, sd, np_, True, NFFT, HOP, WIN, SKIP, "mask", False)
     assert relerr(c.cpu(), want2) < 1e-4
+
+
+def test_end_to_end_encoder_decoder_grads_with_repeated_skips(pm, losses):
+    """Trainable NSVAE encoder -> reparameterised z -> decoder with real skips repeated num_samples times (pad='sig', mask)
+    -> SI-SNR: gradients reach the ENCODER through z and through the repeated skip connections (RepeatBatchFn sums the
+    copies).  Against torch.autograd through the oracle in float64."""
+    nl, _, _ = losses
+    base, zdim, ns, B, L = 4, 32, 2, 2, 1600
+    T = 1 + L // HOP
+    np_ = O.net_params(True, base)
+    enc = load_synth(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns, 2), 31)
+    dec = load_synth(pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, "cuda", ns, zdim, NFFT, HOP, WIN, "mask", True, SKIP, False), 32)
+    g = torch.Generator().manual_seed(2)
+    x = rnd(g, B, L, scale=0.1)
+    clean = x + rnd(g, B, L, scale=0.03)
+    eps = [rnd(g, B, ns, T, zdim) for _ in range(4)]
+    with torch.enable_grad():
+        r = enc(x.cuda(), train=True, eps=tuple(e.cuda() for e in eps))
+        rec, prd = dec(r[11], r[0], r[8], r[9], r[10], train=True, pad='sig')
+        loss = nl.two_phase_loss([0, 0, 1], 1.0, zdim, 1).phase_2_loss(prd, r[11].detach(), clean.cuda(), rec, None, None, None, None)[0]
+        loss.backward()
+    sd_e = {k: leaf64(v.cpu()) for k, v in enc.state_dict().items() if v.dtype.is_floating_point}
+    sd_d = {k: leaf64(v.cpu()) for k, v in dec.state_dict().items() if v.dtype.is_floating_point}
+    oe = O.vae_encoder_forward(x.double(), sd_e, np_, True, zdim, NFFT, HOP, WIN, ns, 2, [e.double() for e in eps], True)
+    o_rec, o_pred = O.vae_decoder_forward(oe["stft_x"], oe["z_speech"], oe["skiper"], 8 * base, 5, sd_d, np_, True, ns, NFFT, HOP, WIN,
+                                          "mask", SKIP, "sig", True, True)
+    check("recon", rec, o_rec, 1e-4)
+    ol = O.si_snr(clean.double().repeat_interleave(ns, 0), o_rec)
+    assert abs(float(loss.detach()) - float(ol)) < 1e-4 * abs(float(ol))
+    ol.backward()
+    n = 0
+    for mod, sd in ((enc, sd_e), (dec, sd_d)):
+        for k, p_ in mod.named_parameters():
+            want = sd[k].grad
+            if want is None or p_.grad is None:
+                assert (want is None or float(want.abs().max()) == 0.0) and (p_.grad is None or float(p_.grad.abs().max()) == 0.0), k
+                continue
+            if k.endswith("conv_re.bias") or k.endswith("conv_im.bias"):
+                continue
+            check(k, p_.grad, want, 1e-3)
+            n += 1
+    assert n > 60

@@ -166,3 +166,14 @@ def test_stock_cpu_baseline_module_matches_the_oracle():
             assert est.shape == want.shape
             assert float((est - want).norm() / want.norm()) < 1e-4
             assert float((pred - wpred).norm() / wpred.norm()) < 1e-4
+
+
+def test_library_is_newer_than_its_sources(amd):
+    """The in-tree libidccrn_hip.so travels to the GPU box as built here: a source edited after the last build() would be
+    tested there against stale device code."""
+    import glob
+    lib = amd._lib.LIB_PATH
+    srcs = glob.glob(os.path.join(ROOT, "i-dccrn-vae_amd", "csrc", "*.hip")) + \
+        glob.glob(os.path.join(ROOT, "i-dccrn-vae_amd", "csrc", "*.hpp")) + [amd._lib.HEADER_PATH]
+    stale = [os.path.basename(f) for f in srcs if os.path.getmtime(f) > os.path.getmtime(lib)]
+    assert not stale, f"rebuild (python __graft_entry__.py): {stale} changed after libidccrn_hip.so was linked"
