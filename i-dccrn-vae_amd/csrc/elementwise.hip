@@ -231,6 +231,41 @@ __global__ void reparam_kernel(const float* __restrict__ lat, int Hl, int off_mi
     }
 }
 
+// Optional input normalisation of DCCRN_.forward (pvae_module.py:217-221):  (stft - mean) / (std + 1e-6) per (bin, part),
+// imaginary part of the first and last bin zeroed;  inverse (:235-238): std * pred + mean, written planar and interleaved.
+__global__ void datanorm_kernel(const float* __restrict__ X, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                int F, int B, int T, int Tp, int Jp, float* __restrict__ out) {
+    const long long n = (long long)B * F * T;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % T);
+        const int f = (int)((idx / T) % F);
+        const int b = (int)(idx / ((long long)T * F));
+        const size_t j = (size_t)f * Jp + (size_t)b * Tp + t + 1;
+        const float r = (X[j] - mean[2 * f]) / (stdv[2 * f] + 1e-6f);
+        float im = (X[(size_t)F * Jp + j] - mean[2 * f + 1]) / (stdv[2 * f + 1] + 1e-6f);
+        if (f == 0 || f == F - 1) im = 0.f;
+        out[j] = r;
+        out[(size_t)F * Jp + j] = im;
+    }
+}
+
+__global__ void datadenorm_kernel(const float* __restrict__ P, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                  int F, int B, int T, int Tp, int Jp, float* __restrict__ out, float* __restrict__ out_c) {
+    const long long n = (long long)B * F * T;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % T);
+        const int f = (int)((idx / T) % F);
+        const int b = (int)(idx / ((long long)T * F));
+        const size_t j = (size_t)f * Jp + (size_t)b * Tp + t + 1;
+        const float r = stdv[2 * f] * P[j] + mean[2 * f];
+        const float im = stdv[2 * f + 1] * P[(size_t)F * Jp + j] + mean[2 * f + 1];
+        out[j] = r;
+        out[(size_t)F * Jp + j] = im;
+        out_c[idx * 2] = r;
+        out_c[idx * 2 + 1] = im;
+    }
+}
+
 __global__ void zero_guard_kernel(float* __restrict__ act, int planes, int B, int Tp, int Jp) {
     const long long n = (long long)planes * B;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x)
@@ -267,6 +302,25 @@ extern "C" int idv_mask_apply(const float* mask, const float* X, int x_div, int 
     hipLaunchKernelGGL(zero_guard_kernel, dim3(grid_for(2LL * F * B)), dim3(256), 0, (hipStream_t)stream, pred, 2 * F, B, Tp, Jp);
     hipLaunchKernelGGL(mask_apply_kernel, dim3(grid_for((long long)B * F * T)), dim3(256), 0, (hipStream_t)stream, mask, X,
                        x_div, JpX, pred, pred_c, F, B, T, Tp, Jp);
+    return idv_launch_status();
+}
+
+extern "C" int idv_datanorm(const float* X, const float* mean, const float* stdv, int F, int B, int T, int Tp, int Jp, float* out,
+                            void* stream) {
+    if (!X || !mean || !stdv || !out || F <= 0 || B <= 0 || T <= 0 || Tp < T + 1) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * 2 * (size_t)F * Jp, st) != hipSuccess) return IDV_ELAUNCH;
+    hipLaunchKernelGGL(datanorm_kernel, dim3(grid_for((long long)B * F * T)), dim3(256), 0, st, X, mean, stdv, F, B, T, Tp, Jp, out);
+    return idv_launch_status();
+}
+
+extern "C" int idv_datadenorm(const float* P, const float* mean, const float* stdv, int F, int B, int T, int Tp, int Jp, float* out,
+                              float* out_c, void* stream) {
+    if (!P || !mean || !stdv || !out || !out_c || F <= 0 || B <= 0 || T <= 0 || Tp < T + 1) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * 2 * (size_t)F * Jp, st) != hipSuccess) return IDV_ELAUNCH;
+    hipLaunchKernelGGL(datadenorm_kernel, dim3(grid_for((long long)B * F * T)), dim3(256), 0, st, P, mean, stdv, F, B, T, Tp, Jp,
+                       out, out_c);
     return idv_launch_status();
 }
 

@@ -51,6 +51,32 @@ __global__ void sisnr_final_kernel(const double* __restrict__ work, int B, float
     out[0] = (float)(-acc / B);
 }
 
+// compute_sisdr (utils/eval_metrics.py:49-64), one value per utterance: a = (eps + <s,e>) / (<s,s> + eps),
+// SI-SDR = 10 log10((eps + a^2 <s,s>) / (eps + |e - a s|^2)), eps = float32 machine epsilon
+__global__ void sisdr_final_kernel(const double* __restrict__ work, int B, float* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double eps = 1.1920928955078125e-07;
+    const double E = work[b * 3], D = work[b * 3 + 1], Q = work[b * 3 + 2];
+    const double a = (eps + D) / (E + eps);
+    const double sss = a * a * E;
+    double snn = Q - 2 * a * D + sss;
+    if (snn < 0) snn = 0;
+    out[b] = (float)(10.0 * log10((eps + sss) / (eps + snn)));
+}
+
+// out[b][n] = mean_s x[b*ns + s][n]   (test_se_cvaefinetune.py:309-311: torch.mean over the sampled waveforms)
+__global__ void mean_over_samples_kernel(const float* __restrict__ x, int ns, int B, int L, float* __restrict__ out) {
+    const long long n = (long long)B * L;
+    const float inv = 1.0f / ns;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / L, k = idx - b * L;
+        float acc = 0.f;
+        for (int s = 0; s < ns; ++s) acc += x[(b * ns + s) * L + k];
+        out[idx] = acc * inv;
+    }
+}
+
 __global__ __launch_bounds__(256) void recon_partial_kernel(const float* __restrict__ pred_c, const float* __restrict__ ori,
                                                             long long sb, long long sf, long long st, long long sr,
                                                             int ori_div, int B, int F, int T, double* __restrict__ work) {
@@ -166,6 +192,23 @@ extern "C" int idv_sisnr(const float* source, int src_ld, int src_div, const flo
     int gx = grid_for(L, 64);
     hipLaunchKernelGGL(sisnr_partial_kernel, dim3(gx, B), dim3(256), 0, st, source, src_ld, src_div, est, est_ld, L, work);
     hipLaunchKernelGGL(sisnr_final_kernel, dim3(1), dim3(64), 0, st, work, B, out);
+    return idv_launch_status();
+}
+
+extern "C" int idv_sisdr(const float* ref, int ref_ld, const float* est, int est_ld, int B, int L, double* work, float* out,
+                         void* stream) {
+    if (!ref || !est || !work || !out || B <= 0 || L <= 0) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(work, 0, sizeof(double) * 3 * B, st) != hipSuccess) return IDV_ELAUNCH;
+    hipLaunchKernelGGL(sisnr_partial_kernel, dim3(grid_for(L, 64), B), dim3(256), 0, st, ref, ref_ld, 1, est, est_ld, L, work);
+    hipLaunchKernelGGL(sisdr_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, work, B, out);
+    return idv_launch_status();
+}
+
+extern "C" int idv_mean_over_samples(const float* x, int ns, int B, int L, float* out, void* stream) {
+    if (!x || !out || ns < 1 || B <= 0 || L <= 0) return IDV_EINVAL;
+    hipLaunchKernelGGL(mean_over_samples_kernel, dim3(grid_for((long long)B * L, 4096)), dim3(256), 0, (hipStream_t)stream, x, ns,
+                       B, L, out);
     return idv_launch_status();
 }
 

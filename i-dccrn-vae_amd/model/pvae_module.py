@@ -281,13 +281,19 @@ class standard_DCCRN(nn.Module):
 
 def _apply_datanorm(stft: Planar, mean, std) -> Planar:
     """Optional input normalisation of DCCRN_.forward (pvae_module.py:217-221); off in the shipped recipes."""
-    v = stft.tensor4()
-    out = Planar.empty(1, stft.F, stft.B, stft.T, stft.Tp, stft.buf.device, zero=True)
-    o = out.tensor4()
-    o.copy_((v - mean) / (std + 1e-6))
-    o[:, 0, :, 1] = 0
-    o[:, -1, :, 1] = 0
+    out = Planar.empty(1, stft.F, stft.B, stft.T, stft.Tp, stft.buf.device)
+    ops.call("idv_datanorm", stft.ptr(), ops.p(mean.reshape(-1).float().contiguous()), ops.p(std.reshape(-1).float().contiguous()),
+             ops.i(stft.F), ops.i(stft.B), ops.i(stft.T), ops.i(stft.Tp), ops.i(stft.Jp), out.ptr(), ops.stream_ptr())
     return out
+
+
+def _invert_datanorm(pred: Planar, mean, std):
+    """predict = data_std * predict + data_mean (pvae_module.py:235-238) -> (planar, complex [B, F, T])."""
+    out = Planar.empty(1, pred.F, pred.B, pred.T, pred.Tp, pred.buf.device)
+    pc = torch.empty(pred.B, pred.F, pred.T, 2, dtype=torch.float32, device=pred.buf.device)
+    ops.call("idv_datadenorm", pred.ptr(), ops.p(mean.reshape(-1).float().contiguous()), ops.p(std.reshape(-1).float().contiguous()),
+             ops.i(pred.F), ops.i(pred.B), ops.i(pred.T), ops.i(pred.Tp), ops.i(pred.Jp), out.ptr(), ops.p(pc), ops.stream_ptr())
+    return out, torch.view_as_complex(pc)
 
 
 def _predict_outputs(module, out: Planar, stft_in: Planar, recon_type: str, x_div: int = 1):
@@ -355,13 +361,13 @@ class DCCRN_(nn.Module):
 
     def _forward_one(self, signal, train, on_encoded=None):
         X = self.stft.planar(signal)
+        if self.datanorm and train and torch.is_grad_enabled():
+            raise NotImplementedError("training with data normalisation (--data_norm is off in the shipped recipe)")
         net_in = _apply_datanorm(X, self.data_mean, self.data_std) if self.datanorm else X
         out = self.std_DCCRN.forward_planar(net_in, train=train, on_encoded=on_encoded)
         pred, predict = _predict_outputs(self, out, net_in, self.recon_type)
         if self.datanorm:
-            pr = torch.view_as_real(predict)
-            pr.copy_(self.data_std * pr + self.data_mean)
-            pred = Planar.from_tensor5(pr.unsqueeze(1), X.Tp)
+            pred, predict = _invert_datanorm(pred, self.data_mean, self.data_std)
         clean = self.istft.planar(pred)
         if self.resynthesis:
             predict = ops.planar_to_complex(self.stft.planar(clean))

@@ -170,6 +170,12 @@ int idv_istft_ola(const float* frames, const float* env_inv, int B, int n_fft, i
  * writes planar `pred` and the interleaved complex64 API tensor pred_c[B][F][T][2]. */
 int idv_mask_apply(const float* mask, const float* X, int x_div, int JpX, float* pred, float* pred_c, int F, int B,
                    int T, int Tp, int Jp, void* stream);
+/* Optional data normalisation of DCCRN_.forward (pvae_module.py:217-221 / :235-238; data_mean, data_std: [F][2] from
+ * dataset/mean_*_spksplit.txt): out = (X - mean) / (std + 1e-6) with the imaginary part of bins 0 and F-1 zeroed, and the
+ * inverse std * P + mean written planar (out) and interleaved [B][F][T][2] (out_c).  Eval path. */
+int idv_datanorm(const float* X, const float* mean, const float* stdv, int F, int B, int T, int Tp, int Jp, float* out, void* stream);
+int idv_datadenorm(const float* P, const float* mean, const float* stdv, int F, int B, int T, int Tp, int Jp, float* out,
+                   float* out_c, void* stream);
 /* planar [2][F][Jp] -> interleaved [B][F][T][2] (recon_type 'real_imag', pvae_module.py:245-253). */
 int idv_planar_to_complex(const float* act, float* out_c, int F, int B, int T, int Tp, int Jp, void* stream);
 
@@ -223,6 +229,11 @@ int idv_reparam(const float* lat, int Hl, int off_miu, int off_ls, int off_dl, i
  * src_div: source row = b / src_div (repeat over num_samples).  work: 3*B doubles (zeroed here). */
 int idv_sisnr(const float* source, int src_ld, int src_div, const float* est, int est_ld, int B, int L, double* work,
               float* out, void* stream);
+/* Enhancement inference.  idv_sisdr: compute_sisdr of utils/eval_metrics.py:49-64 on the device, one value per
+ * utterance (out[B]); work: 3*B doubles.  idv_mean_over_samples: the mean over the num_samples sampled waveforms of one
+ * utterance, i_dccrn_vae/nsvae_dccrn/test_se_cvaefinetune.py:309-311 (x: [B*ns][L] -> out [B][L]). */
+int idv_sisdr(const float* ref, int ref_ld, const float* est, int est_ld, int B, int L, double* work, float* out, void* stream);
+int idv_mean_over_samples(const float* x, int ns, int B, int L, float* out, void* stream);
 /* multiple_recon_loss terms (model/nsvae_loss.py:775-797): out[0] = loss_cpx, out[1] = loss_mag
  * (the original magnitude uses the real part twice, nsvae_loss.py:783).  pred_c: interleaved
  * [B][F][T][2]; ori: element (b,f,t,ri) at ori[(b/ori_div)*sb + f*sf + t*st + ri*sr]. */

@@ -551,6 +551,66 @@ def gen_vae_full(tag, B, ns, seed):
          nsvae=torch.stack([torch.as_tensor(v).float() for v in ln_out[:4]]))
 
 
+def gen_datanorm():
+    """DCCRN_ with data_mean / data_std (pvae_module.py:217-221, :235-238), mask and real_imag outputs, eval mode."""
+    print("== DCCRN_ datanorm")
+    np_ = O.net_params(True, 4)
+    skip = [0, 1, 2, 3, 4, 5]
+    mean = rnd(91, 1, 257, 1, 2, scale=0.05)
+    std = rnd(92, 1, 257, 1, 2, scale=0.2).abs() + 0.5
+    x = rnd(93, 2, 1600, scale=0.1)
+    out = dict(x=x, data_mean=mean, data_std=std, seed=94)
+    for rt in ("mask", "real_imag"):
+        m = R_pm.DCCRN_(NFFT, HOP, np_, True, "cpu", WIN, skip, rt, False, mean, std)
+        sd = O.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items() if v is not None and k not in ("data_mean", "data_std")}, 94)
+        sd["data_mean"], sd["data_std"] = mean, std
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        clean, pred = m(x, train=False)
+        out[f"clean_{rt}"] = clean
+        out[f"pred_{rt}"] = torch.view_as_real(pred)
+    save("dccrn_datanorm_mini", **out)
+
+
+def gen_checkpoint():
+    """A tiny run folder written by the REFERENCE classes exactly as supervised_dccrn/train.py:295-324 writes it
+    (state_dict file + checkpoint dict with optimizer / scheduler state), plus the reference's eval output of the
+    stored weights.  Data only: tensors and bookkeeping scalars."""
+    import shutil
+    print("== checkpoint fixture")
+    np_ = O.net_params(True, 2, 16)
+    skip = [0, 1, 2, 3, 4, 5]
+    folder = os.path.join(HERE, "ckpt", "2025-01-01-00h00_DCCRN_causal=True_skipuse=012345_reconw=001_recontype=mask_resynthesis=False_datanorm=False")
+    shutil.rmtree(os.path.join(HERE, "ckpt"), ignore_errors=True)
+    os.makedirs(folder)
+    with torch.enable_grad():
+        m = R_pm.DCCRN_(NFFT, HOP, np_, True, "cpu", WIN, skip, "mask", False, None, None)
+        load_synth(m, 97)
+        m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0.001)
+        sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, 'min', factor=0.5, patience=3)
+        x = rnd(98, 2, 1600, scale=0.1)
+        c = rnd(99, 2, 1600, scale=0.1)
+        est, pred = m(x, train=True)
+        loss = R_nl.ete_train_se_loss([0.0, 0.0, 1.0]).final_ete_loss(pred, m.stft(c), c, est)[0]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sch.step(float(loss))
+    torch.save(m.state_dict(), os.path.join(folder, "DCCRN_curr_best_epoch.pt"))
+    torch.save({"epoch": 3, "best_val_loss": float(loss), "cpt_patience": 1, "model_state_dict": m.state_dict(),
+                "loss_log": {"train_loss": np.asarray([3.0, 2.0, 1.5, 1.2]), "val_loss": np.asarray([3.1, 2.2, 1.6, 1.3])},
+                "model_optim_dict": opt.state_dict(), "model_scheduler_dict": sch.state_dict()},
+               os.path.join(folder, "DCCRN_checkpoint.pt"))
+    with torch.no_grad():
+        m.eval()
+        xe = rnd(100, 2, 1600, scale=0.1)
+        clean, _ = m(xe, train=False)
+    np.savez_compressed(os.path.join(folder, "expected.npz"), x=xe.numpy(), clean=clean.numpy(),
+                        step1=np.asarray(opt.state_dict()["state"][0]["step"]))
+    print("wrote", folder, sum(os.path.getsize(os.path.join(folder, f)) for f in os.listdir(folder)) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "mini", "full"]
     if "ops" in which:
@@ -567,6 +627,9 @@ if __name__ == "__main__":
     if "grads" in which:
         gen_grad_dccrn("mini", 4, 2, 1600, 61, [0.2, 0.1, 1.0])
         gen_grad_vae("mini", 4, 32, 2, 1600, 2, 71)
+    if "extras" in which:
+        gen_datanorm()
+        gen_checkpoint()
     if "vaefull" in which:
         torch.set_num_threads(os.cpu_count())
         gen_vae_full("full_eval", 1, 2, 81)

@@ -177,3 +177,58 @@ def test_library_is_newer_than_its_sources(amd):
         glob.glob(os.path.join(ROOT, "i-dccrn-vae_amd", "csrc", "*.hpp")) + [amd._lib.HEADER_PATH]
     stale = [os.path.basename(f) for f in srcs if os.path.getmtime(f) > os.path.getmtime(lib)]
     assert not stale, f"rebuild (python __graft_entry__.py): {stale} changed after libidccrn_hip.so was linked"
+
+
+CKPT = os.path.join(ROOT, "tests", "golden", "ckpt",
+                    "2025-01-01-00h00_DCCRN_causal=True_skipuse=012345_reconw=001_recontype=mask_resynthesis=False_datanorm=False")
+
+
+def test_run_folder_parsing_follows_the_reference():
+    """Hyper-parameters live in the run-folder name (supervised_dccrn/test.py:362-393, train_nsvae.py:94-120,
+    train_second_phase_decoder.py:732-775)."""
+    ck = importlib.import_module("i-dccrn-vae_amd.utils.checkpoint")
+    hp = ck.parse_run_folder(CKPT)
+    assert hp["causal"] is True and hp["skipuse"] == [0, 1, 2, 3, 4, 5] and hp["recon_type"] == "mask"
+    assert hp["resynthesis"] is False and hp["datanorm"] is False and hp["reconw"] == "001"
+    hp = ck.parse_run_folder("/x/2024-05-01-10h00_CVAE_causal=True_zdim=128_numsamples=5_klw=1.000_miw=0_skipc=False_"
+                             "skipuse=[0, 1, 2, 3]_spadd=True_recon=real_imag_reconweight=[1.0, 1.0, 0.0]_prior=ri_inde/")
+    assert hp["zdim"] == 128 and hp["num_samples"] == 5 and hp["skipc"] == "False" and hp["skipuse"] == [0, 1, 2, 3]
+    assert hp["spadd"] is True and hp["recon_type"] == "real_imag" and hp["klw"] == 1.0
+    hp = ck.parse_run_folder("2024_NSVAE_causal=True_zdim=128_alpha=1.00_wresi=0.0_wkl=1_wdismiu=0_numsamples=2_nsvae=original_"
+                             "latentnum=2_match=both")
+    assert hp["latent_num"] == 2 and hp["nsvae"] == "original" and hp["alpha"] == 1.0 and hp["match"] == "both"
+    hp = ck.parse_run_folder("2024_P2_causal=True_zdim=128_latentnum=2_decodeupdate=True_skipc=True_skipuse=012345_reconw=001_"
+                             "numsamples=2_loadde=True_recontype=mask_resyn=False")
+    assert hp["decodeupdate"] is True and hp["loadde"] is True and hp["resynthesis"] is False and hp["skipuse"] == [0, 1, 2, 3, 4, 5]
+    assert ck.parse_run_folder("2024_DCCRN_recontype=real")["causal"] is False          # absent keys: the reference's defaults
+    assert ck.parse_run_folder("2024_DCCRN_recontype=real")["recon_type"] == "real_imag"
+
+
+def test_reference_written_checkpoint_loads_and_round_trips(tmp_path):
+    """tests/golden/ckpt/* was written by the REFERENCE's DCCRN_ + Adam + ReduceLROnPlateau
+    (tests/golden/make_golden.py extras): same keys, same shapes -> loads strictly into this package's module."""
+    from oracle import idccrn_oracle as O
+    ck = importlib.import_module("i-dccrn-vae_amd.utils.checkpoint")
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    hp = ck.parse_run_folder(CKPT)
+    m = pm.DCCRN_(NFFT, HOP, O.net_params(True, 2, 16), hp["causal"], "cpu", WIN, hp["skipuse"], hp["recon_type"],
+                  hp["resynthesis"], None, None)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0.001)
+    sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, 'min', factor=0.5, patience=3)
+    info = ck.load_checkpoint(os.path.join(CKPT, "DCCRN_checkpoint.pt"), {"model": m}, {"model": opt}, {"model": sch})
+    assert info["epoch"] == 3 and info["cpt_patience"] == 1 and len(info["loss_log"]["train_loss"]) == 4
+    assert float(opt.state_dict()["state"][0]["step"]) == 1.0 and sch.state_dict()["num_bad_epochs"] == 0
+    bn = m.std_DCCRN.encoders[0].bn
+    assert bn.init_flag is True                       # not part of the state_dict: the reference's behaviour is kept
+    ck.set_bn_init_flag(m, False)
+    assert bn.init_flag is False
+    ref = torch.load(os.path.join(CKPT, "DCCRN_curr_best_epoch.pt"), weights_only=False)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+    p1 = ck.save_checkpoint(str(tmp_path), "DCCRN", 4, 0.5, 0, {"model": m}, {"model": opt}, {"model": sch}, {"train_loss": [1.0]})
+    p2 = ck.save_best_epoch(m, str(tmp_path), "DCCRN")
+    assert os.path.basename(p1) == "DCCRN_checkpoint.pt" and os.path.basename(p2) == "DCCRN_curr_best_epoch.pt"
+    again = torch.load(p1, weights_only=False)
+    assert set(again) == {"epoch", "best_val_loss", "cpt_patience", "loss_log", "model_state_dict", "model_optim_dict",
+                          "model_scheduler_dict"}
+    assert os.path.basename(ck.save_best_epoch(m, str(tmp_path), "NSVAE", "noisy_encoder")) == "NSVAE_noisy_encoder_best_epoch.pt"
