@@ -558,6 +558,12 @@ __global__ void zero_tail_kernel(float* __restrict__ act, int planes, int B, int
 
 int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
     dim3 grid((ra.B + 15) / 16, 4);
+    if ((flags & 1) && !(flags & 8) && cstate && !ra.gsave && idv_lstm_pers_supported(ra.H, ra.B)) {
+        // H = 384 / 768 (VAE encoders), split-bf16 mode: one persistent cooperative launch per layer (lstm_pers.hip);
+        // its exchange buffer lives in the scratch behind cstate (idv_clstm_work_floats covers it: 4*H*Jp floats)
+        return idv_lstm_rec_pers(ra.g, ra.g_run_z, ra.g_run_s, ra.ldg, ra.whh, ra.hout, ra.H, ra.B, ra.T,
+                                 (void*)(cstate + 4LL * ra.B * ra.H), (void*)st);
+    }
     if (ra.H == 128 && (flags & 1)) {
         hipLaunchKernelGGL(lstm_rec_bf16_kernel, grid, dim3(256), 0, st, ra);
     } else if (ra.H == 128) {

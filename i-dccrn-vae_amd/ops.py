@@ -454,6 +454,11 @@ def pack_lstm(sd_get, H: int, K: int, layer: int, device):
     return wih, bih, whh, wih16
 
 
+# bf16x3 mode, H = 384 / 768: one persistent cooperative launch per layer (csrc/lstm_pers.hip) instead of one launch per
+# time step; IDV_LSTM_PERSISTENT=0 keeps the per-step kernels
+LSTM_PERSISTENT = os.environ.get("IDV_LSTM_PERSISTENT", "1") != "0"
+
+
 def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
     """ComplexLSTM forward: x planar with C*F = K feature planes per part -> planar [2][H][Jp] (F = 1)."""
     K = x.C * x.F
@@ -461,7 +466,9 @@ def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
     nwork = L.lib().idv_clstm_work_floats(i(H), i(x.B), i(x.T), i(x.Jp))
     work = torch.empty(bucket(int(nwork)), dtype=torch.float32, device=x.buf.device)
     flags = 1 if PRECISION == "bf16x3" else 0
-    if flags and packed0[3] is not None:
+    if not LSTM_PERSISTENT:
+        flags |= 8
+    if (flags & 1) and packed0[3] is not None:
         # layer-0 input projection on the bf16 MFMA: K-major split image of the 2K input planes, then G into `work`
         kimg = KImage.from_planes(x.ptr(), 2 * K, x.B * x.Tp, x.Jp, x.buf.device)
         call("idv_lstm_proj_bf16x3", kimg.ptr(), ll(kimg.lo_slots), i(K), p(packed0[3]), p(packed0[1]), p(work), i(H), i(x.B),

@@ -183,6 +183,16 @@ int idv_planar_to_complex(const float* act, float* out_c, int F, int B, int T, i
  * imag = ir + ri.  x: planar [2][K][Jp]; out: planar [2][H][Jp].  flags bit 0: split-bf16 recurrence (H = 128).  wihN / bihN: idv_pack_lstm_ih of layer
  * N, whhN: idv_pack_lstm_hh of layer N.  work: idv_clstm_work_floats(H, B, T, Jp) floats. */
 long long idv_clstm_work_floats(int H, int B, int T, int Jp);   /* 24*T*B*H + 4*B*H + 4*H*Jp */
+/* Persistent cooperative recurrence of one layer for H = 384 / 768 (the VAE encoders' 3*zdim / 6*zdim, reference
+ * model/pvae_module.py:1819, :2160-2163), split-bf16 arithmetic: H/16 co-resident workgroups per weight set keep their
+ * W_hh slice in registers for all T steps and exchange h_t through global memory with a per-step arrive counter (bounded
+ * spins; on a time-out the outputs are NaN).  idv_clstm_fwd uses it when flags bit 0 is set and idv_lstm_pers_supported;
+ * flags bit 3 forces the per-step kernel.  g / g_run_z / g_run_s / ldg address the gate pre-activations as G0 / G1 below,
+ * whh_frag: idv_pack_lstm_hh, hout: [4 runs][T*B][H], work: idv_lstm_pers_work_bytes(H, B) bytes, 16-byte aligned. */
+int idv_lstm_pers_supported(int H, int B);
+long long idv_lstm_pers_work_bytes(int H, int B);
+int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh_frag, float* hout, int H,
+                      int B, int T, void* work, void* stream);
 /* flags bit 2 (training forward, exact-fp32 recurrence only): the activated gates (i, f, g, o) and the cell states are kept
  * for idv_lstm_bptt.  work then holds idv_clstm_train_work_floats floats, laid out (TBH = T*B*H)
  *   [G0 16 TBH | G1 16 TBH | h0 4 TBH | h1 4 TBH | c0 4 TBH | c1 4 TBH | scratch]

@@ -258,6 +258,46 @@ def test_clstm_vae_sizes(ops, precision, H, I, T, B):
     assert float(out.planes()[..., 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("H,B,T", [(384, 5, 60), (768, 32, 48), (384, 40, 30), (768, 33, 25)])
+def test_clstm_persistent_matches_per_step(ops, H, B, T):
+    """The persistent cooperative recurrence (lstm_pers.hip: W_hh slices resident in registers, per-step arrive counter)
+    against the per-step kernels on the same split-bf16 inputs; batch sizes that need 1, 2 and 3 batch chunks and a ragged
+    last tile.  Different summation order and bf16x3 vs fp32 recurrent products -> 2e-4."""
+    g = torch.Generator().manual_seed(H + B)
+    I = 64
+    x = torch.randn(T, B, I, 2, generator=g) * 0.5
+    names = [f"lstm_{s}.{w}_l{l}" for s in ("re", "im") for l in (0, 1) for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    sd = {}
+    for n in names:
+        l = int(n[-1])
+        shape = (4 * H, I if l == 0 else H) if "weight_ih" in n else ((4 * H, H) if "weight_hh" in n else (4 * H,))
+        sd[n] = O.synth_tensor(n, shape, 92) * (2.0 if "weight" in n else 1.0)
+    xp = ops.Planar.from_tensor5(x.permute(1, 2, 0, 3).unsqueeze(2).cuda())
+    get = lambda n: sd[n].cuda()
+    keep = (ops.PRECISION, ops.LSTM_PERSISTENT)
+    try:
+        ops.set_precision("bf16x3")
+        p0, p1 = ops.pack_lstm(get, H, I, 0, "cuda"), ops.pack_lstm(get, H, H, 1, "cuda")
+        ops.LSTM_PERSISTENT = False
+        ref = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
+        ops.LSTM_PERSISTENT = True
+        assert amd_lib().idv_lstm_pers_supported(H, B)
+        got = ops.clstm(xp, p0, p1, H).channel_slice(0, H)
+        got2 = ops.clstm(xp, p0, p1, H).channel_slice(0, H)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(keep[0])
+        ops.LSTM_PERSISTENT = keep[1]
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, got2)                               # deterministic (fixed reduction order)
+    assert relerr(got.cpu(), ref.cpu()) < 2e-4
+
+
+def amd_lib():
+    import importlib
+    return importlib.import_module("i-dccrn-vae_amd")._lib.lib()
+
+
 def test_cdense_golden(ops, golden):
     d = golden("op_cdense")
     x, want, seed = T_(d["x"]), T_(d["y"]), int(d["seed"])              # x: [21,16,2]
