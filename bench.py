@@ -58,6 +58,9 @@ def make_inputs(B, seed, device):
     return (clean + noise).to(device), clean.to(device), noise.to(device)
 
 
+STREAM = False      # --stream: every step takes a fresh batch from the host-side synthetic stream through DevicePrefetcher
+
+
 def build_workload(name, B, device, rank):
     """-> (step callable, utterances per step, description dict)"""
     import torch
@@ -188,10 +191,16 @@ def build_workload(name, B, device, rank):
             p_.requires_grad = False
         loss = nl.two_phase_loss([0, 0, 1], 1.0, zdim, 1)
 
+        feed = None
+        if STREAM:
+            dl = importlib.import_module("i-dccrn-vae_amd.dataset.dataload")
+            feed = iter(dl.DevicePrefetcher(dl.SyntheticMixtures(B, LEN, seed=123 + 1000 * rank), device))
+
         def fl():
-            s = se(noisy, train=False)
+            x_noisy, x_clean = (noisy, clean) if feed is None else next(feed)[:2]
+            s = se(x_noisy, train=False)
             recon, pred = dec(s[11], s[0], s[8], s[9], s[10], train=True, pad='sig')
-            return loss.phase_2_loss(pred, s[11], clean, recon, None, None, None, None)[0]
+            return loss.phase_2_loss(pred, s[11], x_clean, recon, None, None, None, None)[0]
         return train_step([dec], fl), B, {"workload": "decoder fine-tune TRAIN step (config 5): frozen NSVAE encoder (eval) + "
                                           "decoder(mask, pad='sig', train) + SI-SNR + backward + Adam", "batch_per_gpu": B}
     raise SystemExit(f"unknown workload {name}")
@@ -350,11 +359,15 @@ def main():
     ap.add_argument("--workload", default="dccrn_cl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 record")
+    ap.add_argument("--stream", action="store_true", help="twophase_train: stream fresh synthetic DNS3-shaped mixtures from the "
+                    "host every step (pinned memory + copy stream) instead of re-using one resident batch")
     ap.add_argument("--precision", default=os.environ.get("IDV_PRECISION", "fp32"), choices=["fp32", "bf16x3"],
                     help="conv contraction arithmetic of the HEADLINE: exact fp32 MFMA (the reference's precision, default), "
                          "or split-bf16 (3 bf16 MFMAs, fp32 accumulate)")
     args = ap.parse_args()
     train = args.workload in TRAIN_WORKLOADS
+    global STREAM
+    STREAM = args.stream
     if args.batch is None:
         args.batch = 32 if train else DEFAULT_BATCH
 
@@ -464,7 +477,7 @@ def main():
             "config": dict(cfg, utterance="4 s @ 16 kHz (64000 samples, 641 frames)",
                            parallelism=(f"data-parallel x{world}: sharded batch, Sync-CBN moment all-reduce, gradient all-reduce (RCCL)"
                                         if train else f"replicas x{world}"),
-                           streams=n_streams, loss=loss_val),
+                           streams=n_streams, loss=loss_val, input=("streamed from the host per step" if args.stream else "resident in HBM")),
             "roofline": roofline,
         }
         if alt is not None:
