@@ -297,6 +297,9 @@ struct StepArgs {
     int t;
 };
 
+// VEC4 (H % 64 == 0; fragments packed by idv_pack_lstm_hh in the [tile][kk/4][lane][4] order): one 16-byte weight load and
+// one ds_read_b128 of h per 4 k-steps instead of 4 + 4 scalar ones -- the step is bound by the latency of these loads
+template <bool VEC4>
 __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const RecArgs& a = sa.r;
@@ -342,18 +345,38 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs sa) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (b0 + row < a.B) v = *(const f32x4*)(hp + (size_t)row * H + 4 * k4);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hT[(4 * k4 + q) * 16 + row] = v[q];
+            for (int q = 0; q < 4; ++q) {
+                if (VEC4) hT[(k4 >> 2) * 256 + (q * 16 + row) * 4 + (k4 & 3)] = v[q];      // k = 4*k4 + q: k-step k4, lane (q, row)
+                else hT[(4 * k4 + q) * 16 + row] = v[q];
+            }
         }
         __syncthreads();
         const int kw = KK / 4;             // k-steps per wave
-        const float* wt = whh + ((size_t)(cs * 8) * KK + wave * kw) * 64 + lane;
-        const float* hk = hT + (size_t)wave * kw * 64 + lane;
-#pragma unroll 8
-        for (int kk = 0; kk < kw; ++kk) {
-            const float av = hk[64 * kk];
+        if (VEC4) {
+            const f32x4* wt = (const f32x4*)whh + ((size_t)(cs * 8) * (KK / 4) + wave * (kw / 4)) * 64 + lane;
+            const f32x4* hk = (const f32x4*)hT + (size_t)wave * (kw / 4) * 64 + lane;
+#pragma unroll 2
+            for (int k4 = 0; k4 < kw / 4; ++k4) {
+                const f32x4 av = hk[64 * k4];
+                f32x4 wv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wt[((size_t)q * KK + kk) * 64], acc[q], 0, 0, 0);
+                for (int q = 0; q < 8; ++q) wv[q] = wt[((size_t)q * (KK / 4) + k4) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[q][j], acc[q], 0, 0, 0);
+            }
+        } else {
+            const float* wt = whh + ((size_t)(cs * 8) * KK + wave * kw) * 64 + lane;
+            const float* hk = hT + (size_t)wave * kw * 64 + lane;
+#pragma unroll 8
+            for (int kk = 0; kk < kw; ++kk) {
+                const float av = hk[64 * kk];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wt[((size_t)q * KK + kk) * 64], acc[q], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -571,13 +594,15 @@ int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
         hipLaunchKernelGGL(lstm_rec_kernel<true>, grid, dim3(256), smem, st, ra);
     } else if (ra.H % 32 == 0 && cstate) {
         const size_t smem = ((size_t)ra.H * 16 + 4 * 8 * 64 * 4) * sizeof(float);
+        const bool vec4 = (ra.H % 64 == 0);            // must match idv_pack_lstm_hh's fragment order
+        auto k = vec4 ? lstm_step_kernel<true> : lstm_step_kernel<false>;
         if (smem > 64 * 1024 &&
-            hipFuncSetAttribute((const void*)lstm_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return IDV_ELAUNCH;
         dim3 sgrid(ra.H / 32, (ra.B + 15) / 16, 4);
         for (int t = 0; t < ra.T; ++t) {
             StepArgs sa{ra, cstate, t};
-            hipLaunchKernelGGL(lstm_step_kernel, sgrid, dim3(256), smem, st, sa);
+            hipLaunchKernelGGL(k, sgrid, dim3(256), smem, st, sa);
         }
     } else {
         const size_t smem = (size_t)3 * ra.H * 16 * sizeof(float);

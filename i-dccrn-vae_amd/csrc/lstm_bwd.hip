@@ -20,18 +20,20 @@ __device__ __forceinline__ int lstm_src_row(int colp, int H) {
     return g * H + ub * 16 + ul;
 }
 
-// whhT[set][unit tile][kk][lane]: lane l supplies B[k = 4*kk + (l>>4)][n = l&15] = W_hh[row(colp = k)][tile*16 + n]
+// whhT[set][unit tile][blk][lane][4]: 16 gate columns (k) per block; lane l = (q = l>>4, n = l&15) holds, for the four MFMA
+// k-steps j of the block, B[k = 16*blk + 4*j + q][n] = W_hh[row(colp = k)][tile*16 + n] -- one 16-byte load per 4 k-steps
 __global__ void pack_lstm_hh_bwd_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im, int H,
                                         float* __restrict__ out) {
-    const int NTL = H / 16, KK = H;      // 4H / 4 k-steps
-    const long long n = 2LL * NTL * KK * 64;
+    const int NTL = H / 16, KB4 = H / 4;      // 4H / 16 blocks
+    const long long n = 2LL * NTL * KB4 * 64 * 4;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
-        const int lane = (int)(idx & 63);
-        long long t = idx >> 6;
-        const int kk = (int)(t % KK); t /= KK;
+        const int j = (int)(idx & 3);
+        const int lane = (int)((idx >> 2) & 63);
+        long long t = idx >> 8;
+        const int blk = (int)(t % KB4); t /= KB4;
         const int tile = (int)(t % NTL);
         const int set = (int)(t / NTL);
-        const int colp = 4 * kk + (lane >> 4), unit = tile * 16 + (lane & 15);
+        const int colp = 16 * blk + 4 * j + (lane >> 4), unit = tile * 16 + (lane & 15);
         const float* w = set ? w_im : w_re;
         out[idx] = w[(size_t)lstm_src_row(colp, H) * H + unit];
     }
@@ -101,13 +103,16 @@ struct BpttArgs {
     const float* dhout;   // [4][T*B][H] gradient arriving at h_t from above
     const float* whhT;    // pack_lstm_hh_bwd
     float* dcs;           // [4][B][H] running dc
-    float* dAT;           // [2][4 runs][b tiles][4H][16]
-    int H, B, T, t, NT;   // NT: 16-unit tiles per workgroup (1 or 2)
+    float* dAT;           // [2][4 runs][b tiles][4H/16 blocks][64 lanes][4]: MFMA A operands of the next launch, 16 B per lane
+    int H, B, T, t;
 };
 
+// NT: 16-unit tiles per workgroup (2 when H % 32 == 0).  A compile-time constant: with a run-time NT the k loop keeps
+// branches, is not unrolled, and every 16-byte load is followed by its own vmcnt(0) (48 serial L2 round trips per step).
+template <int NT>
 __global__ __launch_bounds__(256, 1) void lstm_step_bwd_kernel(const BpttArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4 * 2 * 64 * 4];
-    const int H = a.H, t = a.t, NT = a.NT;
+    const int H = a.H, t = a.t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cs = blockIdx.x, bt = blockIdx.y, b0 = bt * 16, run = blockIdx.z, z = run >> 1, s = run & 1;
@@ -148,15 +153,54 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_kernel(const BpttArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[q][r] = 0.f;
     if (!last) {
-        const int kw = H / 4;                       // k-steps (of 4 gate columns) per wave: 4H/4/4
-        const float* ak = dAT_r + (size_t)wave * kw * 64 + lane;
-        const float* wt = a.whhT + (((size_t)s * (H / 16) + cs * NT) * H + (size_t)wave * kw) * 64 + lane;
-#pragma unroll 8
-        for (int kk = 0; kk < kw; ++kk) {
-            const float av = ak[64 * kk];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wt[(size_t)kk * 64], acc[0], 0, 0, 0);
-            if (NT > 1) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wt[((size_t)H + kk) * 64], acc[1], 0, 0, 0);
+        const int kw4 = H / 16;                     // blocks of 16 gate columns per wave: (4H / 16) / 4
+        const f32x4* ak = (const f32x4*)dAT_r + (size_t)wave * kw4 * 64 + lane;
+        const f32x4* wt = (const f32x4*)a.whhT + (((size_t)s * (H / 16) + cs * NT) * (H / 4) + (size_t)wave * kw4) * 64 + lane;
+        // two interleaved partial sums per tile: consecutive MFMAs never wait on each other's result
+        f32x4 acc2[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc2[q][r] = 0.f;
+        // groups of 4 blocks, the next group's 4 * (1 + NT) 16-byte loads in flight under the current group's MFMAs
+        // (hand-pipelined: hipcc does not runtime-unroll this loop, and a load right before its MFMA costs an L2 round trip)
+        constexpr int GB = 4;
+        f32x4 A[GB], W[NT][GB], An[GB], Wn[NT][GB];
+        auto load = [&](int b0, f32x4 (&a_)[GB], f32x4 (&w_)[NT][GB]) {
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int b = (b0 + u < kw4) ? b0 + u : kw4 - 1;          // ragged tail: reload the last block, not used
+                a_[u] = ak[(size_t)b * 64];
+#pragma unroll
+                for (int q = 0; q < NT; ++q) w_[q][u] = wt[((size_t)q * (H / 4) + b) * 64];
+            }
+        };
+        load(0, A, W);
+        for (int b0 = 0; b0 < kw4; b0 += GB) {
+            load(b0 + GB < kw4 ? b0 + GB : b0, An, Wn);
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                if (b0 + u < kw4) {
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) {
+                            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][j], W[q][u][j], acc[q], 0, 0, 0);
+                            acc2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][j + 1], W[q][u][j + 1], acc2[q], 0, 0, 0);
+                        }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                A[u] = An[u];
+#pragma unroll
+                for (int q = 0; q < NT; ++q) W[q][u] = Wn[q][u];
+            }
         }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q][r] += acc2[q][r];
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) *(f32x4*)&red[((wave * 2 + q) * 64 + lane) * 4] = acc[q];
@@ -191,11 +235,16 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_kernel(const BpttArgs a)
                 dcs[(size_t)(b0 + seq) * H + unit] = dc * gf[r];
             }
         }
-        float* d = dAT_w + (size_t)(ub * 64 + col) * 16 + rq * 4;
-        *(f32x4*)(d) = oi;
-        *(f32x4*)(d + 16 * 16) = of;
-        *(f32x4*)(d + 32 * 16) = og;
-        *(f32x4*)(d + 48 * 16) = oo;
+        // transposed copy for the next launch: gate column colp = (ub*4 + g)*16 + col -> block ub*4 + g, k-step j = col>>2,
+        // lane (q = col&3, seq): offset ((q*16 + seq)*4 + j) inside the 256-float block
+        float* d = dAT_w + (size_t)(ub * 4) * 256 + (size_t)((col & 3) * 16 + rq * 4) * 4 + (col >> 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            d[r * 4] = oi[r];
+            d[256 + r * 4] = of[r];
+            d[512 + r * 4] = og[r];
+            d[768 + r * 4] = oo[r];
+        }
     }
 }
 
@@ -259,12 +308,13 @@ extern "C" int idv_lstm_bptt(float* gates, long long g_run_z, long long g_run_s,
     a.c = cstates; a.dhout = dhout; a.whhT = whhT;
     a.dcs = work; a.dAT = work + 4LL * B * H;
     a.H = H; a.B = B; a.T = T;
-    a.NT = (H % 32 == 0) ? 2 : 1;
+    const int NT = (H % 32 == 0) ? 2 : 1;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(H / (16 * a.NT), (B + 15) / 16, 4);
+    dim3 grid(H / (16 * NT), (B + 15) / 16, 4);
     for (int t = T - 1; t >= 0; --t) {
         a.t = t;
-        hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(256), 0, st, a);
+        if (NT == 2) hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, grid, dim3(256), 0, st, a);
     }
     return idv_launch_status();
 }

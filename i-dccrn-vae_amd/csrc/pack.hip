@@ -106,15 +106,26 @@ __global__ void pack_pw_kernel(PwSrc s, int rowmap, int M, int K, int KS, int Mt
 
 // recurrent weights: whh_frag[set][tile][kk][lane], tile = 16 gate columns (colp order), lane l supplies
 // B[k = 4*kk + (l>>4)][n = l&15] = W_hh[row(colp = tile*16 + n)][k]
-__global__ void pack_lstm_hh_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im, int H,
+// vec4 (H % 64 == 0, H != 128: the sizes the per-step kernel serves): [set][tile][kk/4][lane][4], i.e. the four k-steps
+// 4*kk4 + j of one lane side by side, so the step kernel loads 16 bytes per 4 k-steps
+__global__ void pack_lstm_hh_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im, int H, int vec4,
                                     float* __restrict__ out) {
     const int NT = H / 4;   // tiles of 16 columns over 4H
     const int KK = H / 4;   // k-steps of 4
     const long long n = 2LL * NT * KK * 64;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
-        const int lane = (int)(idx & 63);
-        long long t = idx >> 6;
-        const int kk = (int)(t % KK); t /= KK;
+        int lane, kk;
+        long long t;
+        if (vec4) {
+            const int j = (int)(idx & 3);
+            lane = (int)((idx >> 2) & 63);
+            t = idx >> 8;
+            kk = 4 * (int)(t % (KK / 4)) + j; t /= (KK / 4);
+        } else {
+            lane = (int)(idx & 63);
+            t = idx >> 6;
+            kk = (int)(t % KK); t /= KK;
+        }
         const int tile = (int)(t % NT);
         const int set = (int)(t / NT);
         const int colp = tile * 16 + (lane & 15), k = 4 * kk + (lane >> 4);
@@ -284,8 +295,9 @@ extern "C" int idv_pack_lstm_ih(const float* w_ih_re, const float* b_ih_re, cons
 
 extern "C" int idv_pack_lstm_hh(const float* w_hh_re, const float* w_hh_im, int H, float* whh_frag, void* stream) {
     if (!w_hh_re || !w_hh_im || !whh_frag || H <= 0 || (H % 16)) return IDV_EINVAL;
+    const int vec4 = (H % 64 == 0 && H != 128) ? 1 : 0;        // lstm.hip launch_rec: per-step kernel, VEC4 instantiation
     hipLaunchKernelGGL(pack_lstm_hh_kernel, dim3(grid_for(2LL * 4 * H * H)), dim3(256), 0, (hipStream_t)stream, w_hh_re,
-                       w_hh_im, H, whh_frag);
+                       w_hh_im, H, vec4, whh_frag);
     if (H % 32 == 0)
         hipLaunchKernelGGL(pack_lstm_hh_bf16_kernel, dim3(grid_for(2LL * H * H / 4)), dim3(256), 0, (hipStream_t)stream, w_hh_re,
                            w_hh_im, H, (uint4*)(whh_frag + (size_t)2 * 4 * H * H));
