@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
     constexpr int NRT = 2 * RTR;                 // row tiles per workgroup (2 runs share a weight set)
     constexpr int RPW = (NRT + 3) / 4;           // row tiles a wave finalises
     extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][NRT][4 gates][64 lanes][4]
+    __shared__ int abort_sh;
     const int H = a.H;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
         for (int r = 0; r < 4; ++r) creg[q][r] = 0.f;
 
     bool aborted = false;
+    if (tid == 0) abort_sh = 0;
     for (int t = 0; t < a.T; ++t) {
         // ---- inputs of the cell update (independent of h): issue first
         float gpre[RPW][4][4];
@@ -104,41 +106,57 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
                 while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 1023) == 0) {
-                        if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abort_sh = 1; break; }
                         if (wall_clock64() - t0 > SPIN_LIMIT_CYCLES / 24) {     // wall_clock64 ticks at 100 MHz
                             __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            abort_sh = 1;
                             break;
                         }
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop stale lines of the other XCDs' data
+                // agent-scope acquire: invalidates this CU's vector cache and the stale lines of this XCD's L2, for every
+                // wave of the workgroup (they are behind the barrier below) -- one thread, as in a cooperative grid sync
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
-            if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { aborted = true; break; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (abort_sh) { aborted = true; break; }
             // ---- gates += h_{t-1} W_hh^T : A fragments straight from the exchange buffer (row = lane & 15, 8 k per lane)
             const unsigned short* hx = a.hx + (size_t)((t - 1) & 1) * 2 * 4 * a.Bpad * H;
-#pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) {
+            // A fragments of row tile rt+1 are in flight while row tile rt multiplies (explicit double buffer: left to
+            // itself hipcc issues each (hi, lo) pair right before its 12 MFMAs, i.e. 4 * KBW serial memory round trips)
+            uint4 ah[2][KBW], al[2][KBW];
+            auto load_a = [&](int rt, uint4 (&h_)[KBW], uint4 (&l_)[KBW]) {
                 const int z = rt / RTR, bt = rt - z * RTR;
                 const int run = 2 * z + s;
                 const size_t rowoff = ((size_t)run * a.Bpad + b_base + bt * 16 + col) * H;
 #pragma unroll
                 for (int k = 0; k < KBW; ++k) {
                     const size_t ko = rowoff + 32 * (wave * KBW + k) + 8 * rq;
-                    const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *(const uint4*)(hx + ko));
-                    const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *(const uint4*)(hx + (size_t)4 * a.Bpad * H + ko));
+                    h_[k] = *(const uint4*)(hx + ko);
+                    l_[k] = *(const uint4*)(hx + (size_t)4 * a.Bpad * H + ko);
+                }
+            };
+            load_a(0, ah[0], al[0]);
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                if (rt + 1 < NRT) load_a(rt + 1, ah[(rt + 1) & 1], al[(rt + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);          // the prefetch is issued BEFORE this row tile's MFMAs
+#pragma unroll
+                for (int k = 0; k < KBW; ++k) {
+                    const bf16x8_t vh = __builtin_bit_cast(bf16x8_t, ah[rt & 1][k]);
+                    const bf16x8_t vl = __builtin_bit_cast(bf16x8_t, al[rt & 1][k]);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, wreg[g][k][0]);
                         const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, wreg[g][k][1]);
                         f32x4 c = acc[rt][g];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, bh, c, 0, 0, 0);
                         acc[rt][g] = c;
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- reduce the 4 K-partials through LDS
