@@ -224,8 +224,10 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
     }
 }
 
-// 16-row tiles per run per workgroup: bounded by registers (W_hh slice 192 VGPRs at H = 768 leaves room for 2 x 2 tiles)
-inline int rtr_for(int H, int B) { return B <= 16 ? 1 : ((B <= 32 || H > 384) ? 2 : 4); }
+// 16-row tiles per run per workgroup: 2 (32 sequences per batch chunk; 1 for B <= 16).  More rows per workgroup would
+// halve the workgroup count but not the per-step latency, which is what bounds the step (measured: CVAE, B = 64, H = 384:
+// one chunk of 64 rows 675 utt/s, two chunks of 32 rows faster), and at H = 768 the registers do not allow more.
+inline int rtr_for(int H, int B) { (void)H; return B <= 16 ? 1 : 2; }
 
 }  // namespace idv_pers
 
@@ -274,7 +276,7 @@ extern "C" int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, a);                                                              \
     } while (0)
     if (H == 384) {
-        if (rtr == 1) IDV_PERS_LAUNCH(3, 1); else if (rtr == 2) IDV_PERS_LAUNCH(3, 2); else IDV_PERS_LAUNCH(3, 4);
+        if (rtr == 1) IDV_PERS_LAUNCH(3, 1); else IDV_PERS_LAUNCH(3, 2);
     } else {
         if (rtr == 1) IDV_PERS_LAUNCH(6, 1); else IDV_PERS_LAUNCH(6, 2);
     }

@@ -291,7 +291,7 @@ inline Plan make_plan(int Sp, int Lp, int J, int MS, int ML, int JT) {
     p.SpPad = p.tilesS * MS;
     p.LpPad = p.tilesL * ML;
     p.jtiles = (J + JT - 1) / JT;
-    int want = (2048 + p.tilesS * p.tilesL - 1) / (p.tilesS * p.tilesL);
+    int want = (1024 + p.tilesS * p.tilesL - 1) / (p.tilesS * p.tilesL);
     if (want < 1) want = 1;
     if (want > p.jtiles) want = p.jtiles;
     p.jt_per_split = (p.jtiles + want - 1) / want;
