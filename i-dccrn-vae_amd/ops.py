@@ -733,7 +733,7 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
 
 
 _WORK = {}
-WGRAD_CFG = -97          # LAUNCH_LOG id of the conv weight-gradient kernel (wgrad_kernel<5, 2, 2, 1, 16> + its unpack)
+WGRAD_CFG = -97          # LAUNCH_LOG id of the conv weight-gradient kernel (wgrad_kernel<5, 2, 1, 1, 4, 1, 16, 2> + its unpack)
 
 
 def _scratch(n: int, device, tag="w") -> torch.Tensor:
