@@ -58,9 +58,15 @@ class ConvBlockFn(torch.autograd.Function):
         wfrag, bias = conv.packed(None, cin_used)
         cout = conv.out_channel
         dev = xbuf.device
+        # bf16x3 training mode: forward and data gradient on the split-bf16 MFMA kernels where the shape allows
+        # (every block but the one-channel ends); weight gradients stay on the fp32 MFMA
+        wbf = None
+        if ops.PRECISION == "bf16x3" and ops.bf16_supported(conv._transposed, x.C, skip.C if skip is not None else 0, 1, cout):
+            wbf = conv.packed_bf16(None, cin_used)
         if bn is not None:
             stats = torch.zeros(cout, 5, dtype=torch.float64, device=dev)
-            y = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, stats=stats)
+            y = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, stats=stats,
+                            wfrag_bf16=wbf)
             first = bool(bn.init_flag)
             moments, fold = ops.cbn_finalize(stats, float(y.B) * y.F * y.T, bn, first, bn.momentum)
             bn._stats_gen += 1
@@ -69,7 +75,7 @@ class ConvBlockFn(torch.autograd.Function):
             z = ops.cbn_apply_to(y, fold, slope)
             ctx.save_for_backward(xbuf, skipbuf, w_re, w_im, y.buf, fold, moments, g_rr, g_ri, g_ii, slope)
         else:
-            z = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip)
+            z = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, wfrag_bf16=wbf)
             ctx.save_for_backward(xbuf, skipbuf, w_re, w_im, None, None, None, None, None, None, None)
         ctx.meta = meta
         ctx.zgeom = _geom(z)
@@ -109,19 +115,26 @@ class ConvBlockFn(torch.autograd.Function):
             if not tr:      # conv [Cout][Cin]: adjoint = transposed conv, Cin' = Cout, Cout' = Cin (single source)
                 if skip is not None:
                     raise NotImplementedError("conv blocks take one source")
-                wf, bz = ops.pack_cconv_adjoint(w_re, w_im, cin_total, cout, cout, True)
-                dx = ops.cconv_dgrad(dy, wf, bz, cin_total, False, True)
+                dx = _dgrad(dy, w_re, w_im, cin_total, cout, False)
             else:           # transposed conv [Cin][Cout]: adjoint = conv, Cout' = a slice of Cin, Cin' = Cout
                 per = cout * 10
                 if need_x:
-                    wf, bz = ops.pack_cconv_adjoint(w_re, w_im, x.C, cout, cout, False)
-                    dx = ops.cconv_dgrad(dy, wf, bz, x.C, True, True)
+                    dx = _dgrad(dy, w_re, w_im, x.C, cout, True)
                 if need_s:
                     wr, wi = w_re.reshape(-1)[x.C * per:], w_im.reshape(-1)[x.C * per:]
-                    wf, bz = ops.pack_cconv_adjoint(wr, wi, skip.C, cout, cout, False)
-                    dskip = ops.cconv_dgrad(dy, wf, bz, skip.C, True, True)
+                    dskip = _dgrad(dy, wr, wi, skip.C, cout, True)
         return (None, _fit(dx, xbuf) if dx is not None else None, _fit(dskip, skipbuf) if dskip is not None else None,
                 dw_re, dw_im, db_re, db_im) + grads_bn
+
+
+def _dgrad(dy: Planar, w_re, w_im, cout_adj: int, cin_adj: int, fwd_transposed: bool) -> Planar:
+    """Adjoint operator with conjugate-transposed weights; split-bf16 kernel in bf16x3 mode when the shape allows."""
+    adj_tr = not fwd_transposed
+    if ops.PRECISION == "bf16x3" and ops.bf16_supported(adj_tr, cin_adj, 0, 1, cout_adj):
+        w16 = ops.pack_cconv_bf16_adjoint(w_re, w_im, cout_adj, cin_adj, cin_adj, adj_tr)
+        return ops.cconv_dgrad(dy, None, ops.zero_bias(cout_adj, w_re.device), cout_adj, fwd_transposed, True, wfrag_bf16=w16)
+    wf, bz = ops.pack_cconv_adjoint(w_re, w_im, cout_adj, cin_adj, cin_adj, adj_tr)
+    return ops.cconv_dgrad(dy, wf, bz, cout_adj, fwd_transposed, True)
 
 
 def conv_block(conv, bn, prelu_weight, x: Planar, skip: Optional[Planar], zero_skip: bool) -> Planar:

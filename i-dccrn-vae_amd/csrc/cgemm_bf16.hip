@@ -502,7 +502,7 @@ inline int waste(int n, int t) { return ((n + t - 1) / t) * t - n; }
 // 16*chunk + 8*(l>>5) + 0..7 of tap (kt = tap/5, kf = tap%5: time-tap-major)
 __global__ void pack_cconv_bf16_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im,
                                        const float* __restrict__ fold, int Cout, int Cin_total, int Cin_used,
-                                       int transposed, int nchunk, int Mtiles, uint4* __restrict__ out) {
+                                       int transposed, int nchunk, int Mtiles, uint4* __restrict__ out, int conj) {
     const long long n = (long long)Mtiles * nchunk * 10 * 2 * 64;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
@@ -516,7 +516,7 @@ __global__ void pack_cconv_bf16_kernel(const float* __restrict__ w_re, const flo
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float w = wprime(w_re, w_im, fold, Cout, Cin_total, Cin_used, transposed, m,
-                                   16 * chunk + 8 * (lane >> 5) + j, tap % 5, tap / 5);
+                                   16 * chunk + 8 * (lane >> 5) + j, tap % 5, tap / 5, conj);
             v[j] = split == 0 ? w : w - bf16_round(w);
         }
         uint4 o;
@@ -561,7 +561,21 @@ extern "C" int idv_pack_cconv_bf16(const float* w_re, const float* w_im, const f
     long long g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(pack_cconv_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w_re, w_im, fold, Cout,
-                       Cin_total, Cin_used, transposed, nchunk, Mtiles, (uint4*)wfrag);
+                       Cin_total, Cin_used, transposed, nchunk, Mtiles, (uint4*)wfrag, 0);
+    return idv_launch_status();
+}
+
+// split-bf16 fragments of the ADJOINT operator (data gradient in bf16x3 training): as idv_pack_cconv_adjoint
+extern "C" int idv_pack_cconv_bf16_adjoint(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used,
+                                           int transposed, void* wfrag, void* stream) {
+    if (!w_re || !w_im || !wfrag || Cout <= 0 || Cin_used <= 0 || Cin_used > Cin_total || (Cin_used % 8)) return IDV_EINVAL;
+    const int Mtiles = ((2 * Cout + 127) / 128) * 4;
+    const int nchunk = (2 * Cin_used) / 16;
+    long long n = (long long)Mtiles * nchunk * 10 * 2 * 64;
+    long long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_cconv_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w_re, w_im,
+                       (const float*)nullptr, Cout, Cin_total, Cin_used, transposed, nchunk, Mtiles, (uint4*)wfrag, 1);
     return idv_launch_status();
 }
 

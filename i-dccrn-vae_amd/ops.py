@@ -710,10 +710,29 @@ def pack_cconv_adjoint(w_re, w_im, cout: int, cin_total: int, cin_used: int, tra
     return wfrag, bias
 
 
-def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, causal: bool) -> Planar:
+def pack_cconv_bf16_adjoint(w_re, w_im, cout: int, cin_total: int, cin_used: int, transposed: bool):
+    """Split-bf16 fragments of the adjoint operator (bf16x3 training), see idv_pack_cconv_bf16_adjoint."""
+    L.lib().idv_cconv_bf16_wfrag_bytes.restype = L._L
+    wfrag = torch.empty(int(L.lib().idv_cconv_bf16_wfrag_bytes(i(cout), i(cin_used))), dtype=torch.uint8, device=w_re.device)
+    call("idv_pack_cconv_bf16_adjoint", p(w_re), p(w_im), i(cout), i(cin_total), i(cin_used), i(1 if transposed else 0),
+         p(wfrag), stream_ptr())
+    return wfrag
+
+
+_ZBIAS = {}
+
+
+def zero_bias(cout: int, device):
+    key = (mtiles_alloc(2 * cout), str(device))
+    if key not in _ZBIAS:
+        _ZBIAS[key] = torch.zeros(key[0] * 32, dtype=torch.float32, device=device)
+    return _ZBIAS[key]
+
+
+def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, causal: bool, wfrag_bf16=None) -> Planar:
     """Data gradient of a causal_complex_conv2d / causal_ComplexConvTranspose2d: the adjoint operator on idv_cconv2d_fwd
     (transposed conv reading (dy[t+1], dy[t]) / conv reading (dy[t], dy[t+1]); all T frames kept: column T+1 is the next
-    utterance's zero guard column)."""
+    utterance's zero guard column).  wfrag_bf16: run it on the split-bf16 kernel instead (bf16x3 training mode)."""
     if not causal:
         raise NotImplementedError("data gradients are implemented for the causal blocks")
     adj_transposed = not fwd_transposed
@@ -723,8 +742,11 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
         cfg = L.lib().idv_cconv_config(i(1 if adj_transposed else 0), i(dy.C), i(cout_adj), i(dy.F))
         macs = 4 * dy.C * cout_adj * 10 * dy.B * dy.T * (dy.F if adj_transposed else Fout)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if wfrag_bf16 is not None:
+            cfg = -(1000000 + L.lib().idv_cconv_bf16_config(i(1 if adj_transposed else 0), i(cout_adj), i(dy.F)))
         ev0.record()
-    call("idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(wfrag), p(bias), p(None), out.ptr(), p(None),
+    call("idv_cconv2d_bf16x3_fwd" if wfrag_bf16 is not None else "idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1),
+         p(wfrag_bf16 if wfrag_bf16 is not None else wfrag), p(bias), p(None), out.ptr(), p(None),
          i(1 if adj_transposed else 0), i(0), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(dy.T), stream_ptr())
     if LAUNCH_LOG is not None:
         ev1.record()

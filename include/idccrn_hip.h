@@ -274,6 +274,9 @@ int idv_miu_dist(const float* q1, int H1, int Jp1, int off1, const float* q2, in
  * t_valid_out = T for the causal transposed conv's. */
 int idv_pack_cconv_adjoint(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used, int transposed,
                            float* wfrag, float* bias_out, void* stream);
+/* the same operator as split-bf16 fragments for idv_cconv2d_bf16x3_fwd (training in bf16x3 mode; idv_cconv_bf16_wfrag_bytes) */
+int idv_pack_cconv_bf16_adjoint(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used, int transposed,
+                                void* wfrag, void* stream);
 
 /* WEIGHT gradient of idv_cconv2d_fwd for one source of the channel concat (x: planar [2][Cx][Fin][Jp_x] = channels
  * ci_off .. ci_off+Cx of the weight tensor; dy: planar [2][Cout][Fout][Jp_dy], the gradient at the conv output, i.e. after

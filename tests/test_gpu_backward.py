@@ -69,6 +69,25 @@ def check(name, got, want, tol=GTOL, atol=0.0):
 ])
 def test_conv_block_grads(ops, pm, cp, transposed, cin, cout, F, T, B, skip_c, bn):
     """conv / transposed conv (+ skip concat) + train-mode ComplexBatchNormal + PReLU: every gradient vs oracle autograd."""
+    _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, 2e-5, GTOL)
+
+
+@pytest.mark.parametrize("transposed,cin,cout,F,T,B,skip_c,bn", [
+    (False, 32, 64, 17, 40, 2, 0, True), (True, 64, 32, 5, 70, 2, 64, True), (True, 256, 128, 5, 37, 2, 256, True),
+    (False, 128, 256, 9, 50, 3, 0, True), (True, 64, 64, 9, 33, 2, 64, False),
+])
+def test_conv_block_grads_bf16x3(ops, pm, cp, transposed, cin, cout, F, T, B, skip_c, bn):
+    """The same blocks in bf16x3 training mode (forward + data gradient on the split-bf16 MFMA kernels, weight gradient on
+    the fp32 MFMA): 1e-3 on every gradient (measured ~1e-5)."""
+    keep = ops.PRECISION
+    ops.set_precision("bf16x3")
+    try:
+        _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, 1e-4, 1e-3)
+    finally:
+        ops.set_precision(keep)
+
+
+def _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, ftol, gtol):
     g = torch.Generator().manual_seed(3)
     dev = "cuda"
     cin_tot = cin + skip_c
@@ -118,11 +137,11 @@ def test_conv_block_grads(ops, pm, cp, transposed, cin, cout, F, T, B, skip_c, b
         st = O.cbn_batch_stats(y)
         y = O.cbn_whiten_affine(y, *st, sd["bn.gamma_rr"], sd["bn.gamma_ri"], sd["bn.gamma_ii"], sd["bn.beta_r"], sd["bn.beta_i"])
         y = O.prelu(y, sd["prelu.weight"])
-    check("forward", z.tensor5(), y, 2e-5)
+    check("forward", z.tensor5(), y, ftol)
     (y * R.double()).sum().backward()
-    check("dx", ops.rewrap(xp.buf.grad, xp).tensor5(), x64.grad)
+    check("dx", ops.rewrap(xp.buf.grad, xp).tensor5(), x64.grad, gtol)
     if s64 is not None:
-        check("dskip", ops.rewrap(skp.buf.grad, skp).tensor5(), s64.grad)
+        check("dskip", ops.rewrap(skp.buf.grad, skp).tensor5(), s64.grad, gtol)
     gx = ops.rewrap(xp.buf.grad, xp).planes()
     assert float(gx[..., 0].abs().max()) == 0.0                         # guard column of the gradient stays zero
     params = dict(blk.named_parameters())
@@ -134,7 +153,7 @@ def test_conv_block_grads(ops, pm, cp, transposed, cin, cout, F, T, B, skip_c, b
         got = params[k].grad
         assert got is not None, k
         atol = 1e-4 * float(R.norm()) if (bn and k.endswith(".bias")) else 0.0     # exactly zero in exact arithmetic
-        check(k, got, v.grad, GTOL, atol)
+        check(k, got, v.grad, gtol, atol)
 
 
 # ----------------------------------------------------------------------------- complex LSTM (BPTT)
@@ -529,7 +548,11 @@ def test_end_to_end_encoder_decoder_grads_with_repeated_skips(pm, losses):
     assert n > 60
 
 
-def test_full_width_train_step_grads(pm, losses):
+_FULL_WIDTH_ORACLE = {}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_full_width_train_step_grads(pm, losses, ops, precision):
     """The DCCRN-CL train step at the reference's FULL width (base 32: up to 512-channel blocks, every kernel at the tile
     counts the benchmark runs) on 1 s utterances: loss, input gradient and every parameter gradient against
     torch.autograd through the oracle in float64 on the CPU.
@@ -541,8 +564,20 @@ def test_full_width_train_step_grads(pm, losses):
     (err_probe_block.py: blocks in isolation on the real activations are at 1e-6 except where an element flipped, e.g.
     decoders.4 2e-4, encoders.3 1e-3; the float32 oracle shows the same jumps at other blocks, encoders.2 / .5).  The
     float32 oracle's own deviation from float64 is printed beside ours (4e-4 .. 1.5e-3).  Against the reference's fp32
-    gradients the mini fixtures hold 1e-3 (worst 4e-4)."""
+    gradients the mini fixtures hold 1e-3 (worst 4e-4).
+
+    bf16x3: the same step in split-bf16 training mode (conv forward + data gradient on the bf16 MFMA kernels) under the
+    same bars; the oracle runs once for both."""
     nl, _, _ = losses
+    keep = ops.PRECISION
+    ops.set_precision(precision)
+    try:
+        _full_width(pm, nl)
+    finally:
+        ops.set_precision(keep)
+
+
+def _full_width(pm, nl):
     np_ = O.net_params(True, 32)
     m = load_synth(pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None), 77)
     m.train()
@@ -555,22 +590,25 @@ def test_full_width_train_step_grads(pm, losses):
         est, pred = m(xg, train=True)
         loss = nl.ete_train_se_loss(w).final_ete_loss(pred, m.stft(c.cuda()), c.cuda(), est)[0]
         loss.backward()
-    sd = {k: v.detach().cpu().double().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
-    for k in list(sd):
-        if ".bn.running" in k or k.endswith((".Vrr", ".Vri", ".Vii")):
-            sd[k] = sd[k].detach()
-    # the running buffers were overwritten by the train step; the train-mode oracle does not read them
-    x64 = x.double().clone().requires_grad_(True)
-    o_est, o_pred, _ = O.dccrn_forward(x64, sd, np_, True, NFFT, HOP, WIN, SKIP, "mask", True, O.BNState())
-    o_loss = O.multiple_recon_loss(o_pred, O.stft(c.double(), NFFT, HOP, WIN), c.double(), o_est, w)[0]
-    o_loss.backward()
-    assert abs(float(loss.detach()) - float(o_loss)) < 2e-4 * abs(float(o_loss))
+    if not _FULL_WIDTH_ORACLE:
+        sd = {k: v.detach().cpu().double().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+        for k in list(sd):
+            if ".bn.running" in k or k.endswith((".Vrr", ".Vri", ".Vii")):
+                sd[k] = sd[k].detach()
+        # the running buffers were overwritten by the train step; the train-mode oracle does not read them
+        x64 = x.double().clone().requires_grad_(True)
+        o_est, o_pred, _ = O.dccrn_forward(x64, sd, np_, True, NFFT, HOP, WIN, SKIP, "mask", True, O.BNState())
+        o_loss = O.multiple_recon_loss(o_pred, O.stft(c.double(), NFFT, HOP, WIN), c.double(), o_est, w)[0]
+        o_loss.backward()
+        # yardstick: the SAME oracle in float32 (what the reference's fp32 torch arithmetic amounts to) against float64
+        sd32 = {k: v.detach().float().clone().requires_grad_(v.requires_grad) for k, v in sd.items()}
+        x32 = x.clone().requires_grad_(True)
+        e32, p32, _ = O.dccrn_forward(x32, sd32, np_, True, NFFT, HOP, WIN, SKIP, "mask", True, O.BNState())
+        O.multiple_recon_loss(p32, O.stft(c, NFFT, HOP, WIN), c, e32, w)[0].backward()
+        _FULL_WIDTH_ORACLE.update(sd=sd, x64=x64, o_est=o_est.detach(), o_loss=float(o_loss), sd32=sd32, x32=x32)
+    sd, x64, o_est, o_loss, sd32, x32 = (_FULL_WIDTH_ORACLE[k] for k in ("sd", "x64", "o_est", "o_loss", "sd32", "x32"))
+    assert abs(float(loss.detach()) - o_loss) < 2e-4 * abs(o_loss)
     check("waveform", est, o_est, 1e-4)
-    # yardstick: the SAME oracle in float32 (what the reference's fp32 torch arithmetic amounts to) against float64
-    sd32 = {k: v.detach().float().clone().requires_grad_(v.requires_grad) for k, v in sd.items()}
-    x32 = x.clone().requires_grad_(True)
-    e32, p32, _ = O.dccrn_forward(x32, sd32, np_, True, NFFT, HOP, WIN, SKIP, "mask", True, O.BNState())
-    O.multiple_recon_loss(p32, O.stft(c, NFFT, HOP, WIN), c, e32, w)[0].backward()
 
     def rel(a, b):
         a, b = a.detach().cpu().double(), b.detach().cpu().double()
