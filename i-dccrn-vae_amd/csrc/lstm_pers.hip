@@ -5,19 +5,25 @@
 // weight set, each holding the (i, f, g, o) columns of 16 hidden units for ALL T steps in registers as split-bf16 MFMA
 // fragments (96 / 192 VGPRs per lane) -- one launch per layer instead of one launch per time step.  Per step a workgroup
 //   1. waits until every workgroup of its group (same weight set, same batch chunk) has published h_{t-1}
-//      (monotonic arrive counter in global memory, release / acquire fences at agent scope: the 8 XCDs have private L2s),
+//      (monotonic arrive counter in global memory; the 8 XCDs have private L2s and a CU's L1 is never refreshed, so the
+//      exchange buffer is written with write-through `sc1` 16-byte stores, drained with s_waitcnt vmcnt(0) by every storing
+//      wave, signalled by ONE agent-scope atomic add per workgroup behind the workgroup barrier, polled with an `sc1` load
+//      and read ONLY with `sc1` buffer loads after the poller has joined the workgroup barrier -- the fence-free hand-off
+//      form; no buffer_wbl2 / buffer_inv per step, which cost 2.9 us of the 6.9 us step in the first version),
 //   2. reads h_{t-1} (all H units of its 2 runs x 16*RTR sequences, split-bf16, straight into MFMA A fragments; the 4
 //      waves split K), contracts with its W_hh slice on v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate),
 //   3. reduces the 4 K-partials through LDS, adds the hoisted input projection, runs the cell update with c kept in
 //      registers, and publishes its 16 units of h_t (fp32 for the next layer, split-bf16 for the next step).
 // Every spin is bounded: a workgroup that waits longer than ~0.4 s raises the abort flag, all workgroups drain, and the
 // outputs are poisoned with NaN (no hang; results never silently wrong).
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/idccrn_hip.h"
 
 namespace idv_pers {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 struct PersArgs {
     const float* g;           // gate pre-activations (hoisted input projection)
@@ -25,19 +31,31 @@ struct PersArgs {
     int ldg;
     const uint4* whh16;       // split-bf16 fragments of idv_pack_lstm_hh: [set][tile = ub*4 + gate][kb][hi|lo][lane]
     float* hout;              // [4 runs][T*B][H]
-    unsigned short* hx;       // exchange [2 parity][hi|lo][4 runs][Bpad][H] bf16
-    unsigned* sync;           // [2 sets * chunks] arrive counters, then [1] abort flag
+    unsigned short* hx;       // exchange [2 parity][4 runs][Bpad][H/8][hi 8 x bf16 | lo 8 x bf16]
+    unsigned hx_bytes;
+    unsigned* sync;           // [abort flag: 256 B][group = set * chunks + chunk][replica][256 B] arrive counters
+    int nrep;                 // replicas of each arrive counter (1, 2, 4 or 8), each on a 256-byte block of its own
     int H, B, T, Bpad, nchunks;
+    unsigned long long* prof; // diagnostic build only: [workgroup][8] accumulated phase cycles, [7] = XCC id
 };
 
 constexpr unsigned long long SPIN_LIMIT_CYCLES = 1000000000ull;     // ~0.4 s at 2.4 GHz
 
-template <int KBW, int RTR>     // k-blocks (32) per wave = H/128; 16-row tiles per run per workgroup
+#define IDV_STAMP(i)                                                       \
+    if (PROF && pw) {                                                      \
+        const unsigned long long now_ = __builtin_readcyclecounter();      \
+        pacc[i] += now_ - plast;                                           \
+        plast = now_;                                                      \
+    }
+
+template <int KBW, int NRT, bool PROF = false>     // k-blocks (32) per wave = H/128; 16-row tiles per workgroup
 __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
-    constexpr int NRT = 2 * RTR;                 // row tiles per workgroup (2 runs share a weight set)
-    constexpr int RPW = (NRT + 3) / 4;           // row tiles a wave finalises
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][NRT][4 gates][64 lanes][4]
+    // the 2 runs of a weight set (real / imaginary input) x ceil(B/16) row tiles form one tile space of NT = 2 * TPR tiles;
+    // a workgroup owns NRT consecutive tiles of it (its batch chunk)
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][NRT][4 gates][4 rows r][64 lanes]
     __shared__ int abort_sh;
+    __shared__ __attribute__((aligned(16))) unsigned short stage[NRT][2][16][16];   // [tile][hi|lo][row][unit]
+    const __amdgpu_buffer_rsrc_t hxr = __builtin_amdgcn_make_buffer_rsrc((void*)a.hx, 0, a.hx_bytes, 0x00020000);
     const int H = a.H;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,10 +63,28 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
     const int nslice = gridDim.x;
     const int col = lane & 15, rq = lane >> 4;
     const int KB = H / 32;
-    unsigned* counter = a.sync + s * a.nchunks + ch;
-    unsigned* abortf = a.sync + 2 * a.nchunks;
+    const int TPR = a.Bpad / 16, NT = 2 * TPR;
+    // every arriving workgroup adds to ALL replicas of its group's counter (one wave instruction, one lane per replica);
+    // a workgroup polls ONE replica: 1/nrep of the pollers per word, and no two groups share a memory channel (with the four
+    // group counters in one 16-byte block the poll round trip grew by 28 ns per polling workgroup of the LAUNCH: 2.8 us of
+    // a 6.2 us step at 96 workgroups)
+    unsigned* abortf = a.sync;
+    unsigned* counter0 = a.sync + 64 + (size_t)((s * a.nchunks + ch) * a.nrep) * 64;
+    unsigned* counter = counter0 + (size_t)(sl & (a.nrep - 1)) * 64;
     const size_t TBH = (size_t)a.T * a.B * H;
-    const int b_base = ch * 16 * RTR;
+
+    // this workgroup's tiles: run (2 z + s), first row, validity (the last chunk of an odd tile count is ragged)
+    int t_run[NRT], t_b0[NRT];
+    bool t_ok[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+        int tile = ch * NRT + rt;
+        t_ok[rt] = tile < NT;
+        if (tile >= NT) tile = NT - 1;
+        const int z = tile / TPR;
+        t_run[rt] = 2 * z + s;
+        t_b0[rt] = (tile - z * TPR) * 16;
+    }
 
     // W_hh slice: gate tiles (sl*4 + g), this wave's k-blocks
     uint4 wreg[4][KBW][2];
@@ -62,32 +98,30 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
                 for (int sp = 0; sp < 2; ++sp)
                     wreg[g][k][sp] = wb[((size_t)((sl * 4 + g) * KB + wave * KBW + k) * 2 + sp) * 64];
     }
-    float creg[RPW][4];
+    // the cell update is split by ROW over the waves: wave w owns rows rq * 4 + w of every tile (unit = lane & 15), so the
+    // transcendental work (5 exp2 + 5 rcp per element, quarter rate) is spread over all four SIMDs whatever NRT is
+    float creg[NRT];
 #pragma unroll
-    for (int q = 0; q < RPW; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) creg[q][r] = 0.f;
+    for (int rt = 0; rt < NRT; ++rt) creg[rt] = 0.f;
+    const int myrow = rq * 4 + wave;
 
     bool aborted = false;
     if (tid == 0) abort_sh = 0;
+    const bool pw = PROF && wave == 0;
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = 0;
+    if (PROF && pw) plast = __builtin_readcyclecounter();
     for (int t = 0; t < a.T; ++t) {
         // ---- inputs of the cell update (independent of h): issue first
-        float gpre[RPW][4][4];
+        float gpre[NRT][4];
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            const int rt = wave + 4 * q;
-            if (rt < NRT) {
-                const int z = rt / RTR, bt = rt - z * RTR;
-                const float* g = a.g + z * a.g_run_z + s * a.g_run_s;
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int z = t_run[rt] >> 1;
+            const float* g = a.g + z * a.g_run_z + s * a.g_run_s;
+            int b = t_b0[rt] + myrow;
+            if (b >= a.B) b = a.B - 1;
+            const float* gp = g + ((size_t)t * a.B + b) * a.ldg + sl * 64 + col;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int b = b_base + bt * 16 + rq * 4 + r;
-                    if (b >= a.B) b = a.B - 1;
-                    const float* gp = g + ((size_t)t * a.B + b) * a.ldg + sl * 64 + col;
-#pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) gpre[q][gg][r] = gp[16 * gg];
-                }
-            }
+            for (int gg = 0; gg < 4; ++gg) gpre[rt][gg] = gp[16 * gg];
         }
         f32x4 acc[NRT][4];
 #pragma unroll
@@ -114,37 +148,44 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
                         }
                     }
                 }
-                // agent-scope acquire: invalidates this CU's vector cache and the stale lines of this XCD's L2, for every
-                // wave of the workgroup (they are behind the barrier below) -- one thread, as in a cooperative grid sync
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                IDV_STAMP(0)                                 // gpre issue + spin
             }
+            // no acquire fence: every byte of the exchange buffer was stored sc1 and drained before the arrive, and every
+            // load of it below is an sc1 buffer load issued after this barrier, which the polling wave joins after its match
             __syncthreads();
             if (abort_sh) { aborted = true; break; }
+            IDV_STAMP(2)
             // ---- gates += h_{t-1} W_hh^T : A fragments straight from the exchange buffer (row = lane & 15, 8 k per lane)
-            const unsigned short* hx = a.hx + (size_t)((t - 1) & 1) * 2 * 4 * a.Bpad * H;
-            // A fragments of row tile rt+1 are in flight while row tile rt multiplies (explicit double buffer: left to
-            // itself hipcc issues each (hi, lo) pair right before its 12 MFMAs, i.e. 4 * KBW serial memory round trips)
-            uint4 ah[2][KBW], al[2][KBW];
+            const unsigned par_r = (unsigned)((t - 1) & 1) * 4u * (unsigned)a.Bpad * (unsigned)H * 4u;
+            // every row tile's fragments are in flight at once where the registers allow (<= 96 VGPRs), else the fragments of
+            // row tile rt+1 are in flight while row tile rt multiplies (left to itself hipcc issues each (hi, lo) pair right
+            // before its 12 MFMAs, i.e. 4 * KBW serial memory round trips)
+            constexpr bool ALL_UP = (NRT * KBW <= 12);
+            constexpr int NB = ALL_UP ? NRT : 2;
+            uint4 ah[NB][KBW], al[NB][KBW];
             auto load_a = [&](int rt, uint4 (&h_)[KBW], uint4 (&l_)[KBW]) {
-                const int z = rt / RTR, bt = rt - z * RTR;
-                const int run = 2 * z + s;
-                const size_t rowoff = ((size_t)run * a.Bpad + b_base + bt * 16 + col) * H;
+                const unsigned rowoff = ((unsigned)t_run[rt] * a.Bpad + t_b0[rt] + col) * (unsigned)(H / 8);
 #pragma unroll
                 for (int k = 0; k < KBW; ++k) {
-                    const size_t ko = rowoff + 32 * (wave * KBW + k) + 8 * rq;
-                    h_[k] = *(const uint4*)(hx + ko);
-                    l_[k] = *(const uint4*)(hx + (size_t)4 * a.Bpad * H + ko);
+                    const unsigned ko = (rowoff + 4 * (wave * KBW + k) + rq) * 32u;
+                    h_[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(hxr, ko, par_r, 16));
+                    l_[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(hxr, ko + 16u, par_r, 16));
                 }
             };
-            load_a(0, ah[0], al[0]);
+            if (ALL_UP) {
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) load_a(rt, ah[rt % NB], al[rt % NB]);
+            } else {
+                load_a(0, ah[0], al[0]);
+            }
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
-                if (rt + 1 < NRT) load_a(rt + 1, ah[(rt + 1) & 1], al[(rt + 1) & 1]);
+                if (!ALL_UP && rt + 1 < NRT) load_a(rt + 1, ah[(rt + 1) % NB], al[(rt + 1) % NB]);
                 __builtin_amdgcn_sched_barrier(0);          // the prefetch is issued BEFORE this row tile's MFMAs
 #pragma unroll
                 for (int k = 0; k < KBW; ++k) {
-                    const bf16x8_t vh = __builtin_bit_cast(bf16x8_t, ah[rt & 1][k]);
-                    const bf16x8_t vl = __builtin_bit_cast(bf16x8_t, al[rt & 1][k]);
+                    const bf16x8_t vh = __builtin_bit_cast(bf16x8_t, ah[rt % NB][k]);
+                    const bf16x8_t vl = __builtin_bit_cast(bf16x8_t, al[rt % NB][k]);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, wreg[g][k][0]);
@@ -158,127 +199,162 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            IDV_STAMP(3)                                     // A loads + MFMA
         }
-        // ---- reduce the 4 K-partials through LDS
+        // ---- reduce the 4 K-partials through LDS; layout [wave][tile][gate][r][lane]: conflict-free dword writes and reads
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *(f32x4*)&red[(((wave * NRT + rt) * 4 + g) * 64 + lane) * 4] = acc[rt][g];
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((((wave * NRT + rt) * 4 + g) * 4 + r) << 6) + lane] = acc[rt][g][r];
         __syncthreads();
-        unsigned short* hxw = a.hx + (size_t)(t & 1) * 2 * 4 * a.Bpad * H;
+        const unsigned par_w = (unsigned)(t & 1) * 4u * (unsigned)a.Bpad * (unsigned)H * 4u;     // byte offset of parity t & 1
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            const int rt = wave + 4 * q;
-            if (rt < NRT) {
-                const int z = rt / RTR, bt = rt - z * RTR;
-                const int run = 2 * z + s;
-                f32x4 gate[4];
+        for (int rt = 0; rt < NRT; ++rt) {
+            float gate[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 4; ++g) {
+                float v = gpre[rt][g];
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const f32x4 p = *(const f32x4*)&red[(((w * NRT + rt) * 4 + g) * 64 + lane) * 4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += p[r];
-                    }
-                    gate[g] = v;
-                }
-                const int unit = sl * 16 + col;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int b = b_base + bt * 16 + rq * 4 + r;
-                    const float ig = sigmoidf_(gate[0][r] + gpre[q][0][r]), fg = sigmoidf_(gate[1][r] + gpre[q][1][r]);
-                    const float gv = tanhf_(gate[2][r] + gpre[q][2][r]), og = sigmoidf_(gate[3][r] + gpre[q][3][r]);
-                    const float cn = fg * creg[q][r] + ig * gv;
-                    creg[q][r] = cn;
-                    const float hv = og * tanhf_(cn);
-                    if (b < a.B) a.hout[(size_t)run * TBH + ((size_t)t * a.B + b) * H + unit] = hv;
-                    const __bf16 hh = (__bf16)hv;
-                    const __bf16 hl = (__bf16)(hv - (float)hh);
-                    const size_t o = ((size_t)run * a.Bpad + b) * H + unit;          // b < Bpad by construction
-                    hxw[o] = __builtin_bit_cast(unsigned short, hh);
-                    hxw[(size_t)4 * a.Bpad * H + o] = __builtin_bit_cast(unsigned short, hl);
-                }
+                for (int w = 0; w < 4; ++w) v += red[((((w * NRT + rt) * 4 + g) * 4 + wave) << 6) + lane];
+                gate[g] = v;
             }
+            const float ig = sigmoidf_(gate[0]), fg = sigmoidf_(gate[1]);
+            const float gv = tanhf_(gate[2]), og = sigmoidf_(gate[3]);
+            const float cn = fg * creg[rt] + ig * gv;
+            creg[rt] = cn;
+            const float hv = og * tanhf_(cn);
+            const __bf16 hh = (__bf16)hv;
+            const __bf16 hl = (__bf16)(hv - (float)hh);
+            // transpose through LDS: a lane holds one unit of one row, a 16-byte store wants 8 units of a row
+            stage[rt][0][myrow][col] = __builtin_bit_cast(unsigned short, hh);
+            stage[rt][1][myrow][col] = __builtin_bit_cast(unsigned short, hl);
+            const int b = t_b0[rt] + myrow;
+            if (t_ok[rt] && b < a.B) a.hout[(size_t)t_run[rt] * TBH + ((size_t)t * a.B + b) * H + sl * 16 + col] = hv;
         }
-        // ---- publish: all stores of this workgroup, then release + arrive
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave < NRT && t_ok[wave < NRT ? wave : 0]) {
+            // lanes 0..31: hi halves, 32..63: lo halves; (row, 8-unit chunk) = ((lane & 31) >> 1, lane & 1); 16-byte
+            // write-through (sc1) stores: the exchange buffer never sits dirty in this XCD's L2
+            const int rt = wave;
+            const int sp = lane >> 5, row = (lane & 31) >> 1, c8 = lane & 1;
+            const v4i pk = *(const v4i*)&stage[rt][sp][row][c8 * 8];
+            const unsigned off = (((unsigned)t_run[rt] * a.Bpad + t_b0[rt] + row) * (unsigned)(H / 8) + sl * 2 + c8) * 32u + sp * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(pk, hxr, off, par_w, 16);       // aux 16 = sc1
         }
+        // ---- publish: every storing wave drains its stores, the workgroup meets, ONE wave instruction arrives
+        IDV_STAMP(4)                                         // LDS reduction + cell update + stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        IDV_STAMP(5)                                         // store drain + barrier
+        if (tid < a.nrep) __hip_atomic_fetch_add(counter0 + (size_t)tid * 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (PROF && pw && lane == 0) {
+        const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (int i = 0; i < 7; ++i) a.prof[wg * 8 + i] = pacc[i];
+        a.prof[wg * 8 + 7] = __builtin_amdgcn_s_getreg(6164) & 15;      // HW_REG_XCC_ID (id 20, offset 0, size 4)
     }
     if (aborted) {
         // poison this workgroup's outputs: a timed-out recurrence must never look like a result
         const float qnan = __builtin_nanf("");
-        for (int z = 0; z < 2; ++z)
-            for (long long e = tid; e < (long long)a.T * 16 * RTR * 16; e += 256) {
-                const int u = (int)(e & 15);
-                const long long rest = e >> 4;
-                const int br = (int)(rest % (16 * RTR));
-                const long long t = rest / (16 * RTR);
-                const int b = b_base + br;
-                if (b < a.B) a.hout[(size_t)(2 * z + s) * TBH + ((size_t)t * a.B + b) * H + sl * 16 + u] = qnan;
+        for (int rt = 0; rt < NRT; ++rt) {
+            if (!t_ok[rt]) continue;
+            for (long long e = tid; e < (long long)a.T * 16 * 16; e += 256) {
+                const int u = (int)(e & 15), br = (int)((e >> 4) & 15);
+                const long long t = e >> 8;
+                const int b = t_b0[rt] + br;
+                if (b < a.B) a.hout[(size_t)t_run[rt] * TBH + ((size_t)t * a.B + b) * H + sl * 16 + u] = qnan;
             }
+        }
     }
 }
 
-// 16-row tiles per run per workgroup: 2 (32 sequences per batch chunk; 1 for B <= 16).  More rows per workgroup would
-// halve the workgroup count but not the per-step latency, which is what bounds the step (measured: CVAE, B = 64, H = 384:
-// one chunk of 64 rows 675 utt/s, two chunks of 32 rows faster), and at H = 768 the registers do not allow more.
-inline int rtr_for(int H, int B) { (void)H; return B <= 16 ? 1 : 2; }
+// 16-row tiles per workgroup: as few as the residency bound allows (every workgroup must be resident at once: <= 240 of the
+// 256 CUs, one workgroup each).  The step is bound by each CU's read of h_{t-1} (rows x H x 4 bytes of freshly handed-off
+// data at ~20 bytes / cycle / CU) and by fixed hand-off latencies, so fewer rows per workgroup on more CUs is faster:
+// H = 384, B = 32: 1 tile (192 workgroups); H = 768, B = 32: 2 (192); H = 768, B = 64: 4 (192).
+inline int nrt_for(int H, int B) {
+    static const int forced = [] { const char* e = getenv("IDV_PERS_NRT"); return e ? atoi(e) : 0; }();
+    const int NT = 2 * ((B + 15) / 16);
+    for (int nrt = 1; nrt <= 4; nrt *= 2) {
+        if (forced > nrt) continue;
+        if (2 * (H / 16) * ((NT + nrt - 1) / nrt) <= 240) return nrt;
+    }
+    return 0;
+}
 
 }  // namespace idv_pers
 
 extern "C" int idv_lstm_pers_supported(int H, int B) {
     if (H != 384 && H != 768) return 0;
     if (B <= 0) return 0;
-    const int rtr = idv_pers::rtr_for(H, B);
-    const int chunks = (B + 16 * rtr - 1) / (16 * rtr);
-    return 2 * (H / 16) * chunks <= 240;          // every workgroup must be resident at once (256 CUs, one each)
+    return idv_pers::nrt_for(H, B) > 0;
 }
 
+static constexpr int SYNC_BYTES = 256 + 20 * 8 * 256;     // abort flag + (<= 20 groups) x (<= 8 replicas) x 256 B
+
 extern "C" long long idv_lstm_pers_work_bytes(int H, int B) {
-    const int rtr = idv_pers::rtr_for(H, B);
-    const int chunks = (B + 16 * rtr - 1) / (16 * rtr);
-    const long long Bpad = (long long)chunks * 16 * rtr;
-    return 2LL * 2 * 4 * Bpad * H * 2 + (2LL * chunks + 2) * 4 + 64;
+    const long long Bpad = (B + 15) / 16 * 16;
+    return SYNC_BYTES + 2LL * 4 * Bpad * H * 4;       // [abort flag + arrive counters, zeroed per call][exchange]
 }
+
+static unsigned long long* g_prof = nullptr;
+
+// diagnostic: while a device buffer of 256 x 8 counters is registered, idv_lstm_rec_pers launches the instrumented twin of
+// the kernel, in which wave 0 of every workgroup (index (chunk * 2 + set) * H/16 + slice) accumulates the core-clock cycles
+// it spends per phase over the T steps: [0] gate-input issue + spin on the arrive counter, [2] barrier, [3] h loads + MFMA,
+// [4] LDS reduction + cell update + store issue, [5] store drain + barrier; [7] = the XCC the workgroup ran on.
+// nullptr restores the production kernel.
+extern "C" void idv_lstm_pers_set_profile(unsigned long long* prof_cycles) { g_prof = prof_cycles; }
 
 // one layer of the recurrence; work: idv_lstm_pers_work_bytes(H, B) bytes (16-byte aligned), contents arbitrary
 extern "C" int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh_frag, float* hout,
                                  int H, int B, int T, void* work, void* stream) {
     using namespace idv_pers;
+    unsigned long long* prof = g_prof;
     if (!g || !whh_frag || !hout || !work || T <= 0 || !idv_lstm_pers_supported(H, B)) return IDV_EINVAL;
     if (reinterpret_cast<uintptr_t>(work) & 15) return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int rtr = rtr_for(H, B);
-    const int chunks = (B + 16 * rtr - 1) / (16 * rtr);
-    const long long Bpad = (long long)chunks * 16 * rtr;
-    const size_t hx_bytes = (size_t)2 * 2 * 4 * Bpad * H * 2;
-    if (hipMemsetAsync(work, 0, (size_t)idv_lstm_pers_work_bytes(H, B), st) != hipSuccess) return IDV_ELAUNCH;
+    const int nrt = nrt_for(H, B);
+    const int TPR = (B + 15) / 16, NT = 2 * TPR;
+    const int chunks = (NT + nrt - 1) / nrt;
+    const long long Bpad = (long long)TPR * 16;
+    const size_t hx_bytes = (size_t)2 * 4 * Bpad * H * 4;
+    if (2 * chunks > 20) return IDV_EINVAL;
+    // only the polled words are zeroed: every row of the exchange buffer a step reads was written by the step before
+    if (hipMemsetAsync(work, 0, SYNC_BYTES, st) != hipSuccess) return IDV_ELAUNCH;
+    static const int nrep = [] {
+        const char* e = getenv("IDV_PERS_REPL");
+        const int v = e ? atoi(e) : 8;
+        return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 8;
+    }();
     PersArgs a{};
     a.g = g; a.g_run_z = g_run_z; a.g_run_s = g_run_s; a.ldg = ldg;
     a.whh16 = (const uint4*)(whh_frag + (size_t)2 * 4 * H * H);
     a.hout = hout;
-    a.hx = (unsigned short*)work;
-    a.sync = (unsigned*)((char*)work + hx_bytes);
-    a.H = H; a.B = B; a.T = T; a.Bpad = (int)Bpad; a.nchunks = chunks;
+    a.sync = (unsigned*)work;
+    a.hx = (unsigned short*)((char*)work + SYNC_BYTES);
+    a.hx_bytes = (unsigned)hx_bytes;
+    a.nrep = nrep;
+    a.H = H; a.B = B; a.T = T; a.Bpad = (int)Bpad; a.nchunks = chunks; a.prof = prof;
     dim3 grid(H / 16, 2, chunks);
-    const size_t smem = (size_t)4 * 2 * rtr * 4 * 64 * 4 * sizeof(float);
-#define IDV_PERS_LAUNCH(KBW, RTR)                                                                                         \
+    // at least 84 KB of LDS per workgroup: ONE workgroup per CU whatever the register count (the hand-off form above is the
+    // one measured for one workgroup per CU, and co-located workgroups would share one CU's miss bandwidth)
+    size_t smem = (size_t)4 * nrt * 4 * 4 * 64 * sizeof(float);
+    if (smem < 84 * 1024) smem = 84 * 1024;
+#define IDV_PERS_LAUNCH(KBW, NRT)                                                                                         \
     do {                                                                                                                  \
-        auto k = lstm_pers_kernel<KBW, RTR>;                                                                              \
-        if (smem > 64 * 1024 &&                                                                                           \
+        auto k = prof ? lstm_pers_kernel<KBW, NRT, true> : lstm_pers_kernel<KBW, NRT, false>;                             \
+        if (smem > 48 * 1024 &&                                                                                           \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)     \
             return IDV_ELAUNCH;                                                                                           \
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, a);                                                              \
     } while (0)
     if (H == 384) {
-        if (rtr == 1) IDV_PERS_LAUNCH(3, 1); else IDV_PERS_LAUNCH(3, 2);
+        if (nrt == 1) IDV_PERS_LAUNCH(3, 1); else if (nrt == 2) IDV_PERS_LAUNCH(3, 2); else IDV_PERS_LAUNCH(3, 4);
     } else {
-        if (rtr == 1) IDV_PERS_LAUNCH(6, 1); else IDV_PERS_LAUNCH(6, 2);
+        if (nrt == 1) IDV_PERS_LAUNCH(6, 1); else if (nrt == 2) IDV_PERS_LAUNCH(6, 2); else IDV_PERS_LAUNCH(6, 4);
     }
 #undef IDV_PERS_LAUNCH
     return idv_launch_status();

@@ -193,6 +193,10 @@ int idv_lstm_pers_supported(int H, int B);
 long long idv_lstm_pers_work_bytes(int H, int B);
 int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh_frag, float* hout, int H,
                       int B, int T, void* work, void* stream);
+/* diagnostic (not part of the drop-in boundary): while a device buffer of 256 x 8 counters is registered, idv_lstm_rec_pers runs
+ * an instrumented twin in which every workgroup accumulates core-clock cycles per phase (spin, -, barrier, loads + MFMA,
+ * reduce + cell, drain + barrier, -, XCC id); NULL restores the production kernel.  tests/tools/lstm_phase_probe.py */
+void idv_lstm_pers_set_profile(unsigned long long* prof_cycles);
 /* flags bit 2 (training forward, exact-fp32 recurrence only): the activated gates (i, f, g, o) and the cell states are kept
  * for idv_lstm_bptt.  work then holds idv_clstm_train_work_floats floats, laid out (TBH = T*B*H)
  *   [G0 16 TBH | G1 16 TBH | h0 4 TBH | h1 4 TBH | c0 4 TBH | c1 4 TBH | scratch]
