@@ -239,7 +239,7 @@ class LstmFn(torch.autograd.Function):
         nwork = ops._ll_fn("idv_clstm_train_work_floats")(i(H), i(x.B), i(x.T), i(x.Jp))
         work = torch.empty(int(nwork), dtype=torch.float32, device=xbuf.device)
         call("idv_clstm_fwd", x.ptr(), i(K), p(p0[0]), p(p0[1]), p(p0[2]), p(p1[0]), p(p1[1]), p(p1[2]), i(H), i(x.B), i(x.T),
-             i(x.Tp), i(x.Jp), p(work), out.ptr(), i(4), stream_ptr())
+             i(x.Tp), i(x.Jp), p(work), out.ptr(), i(4), p(None), stream_ptr())
         ctx.save_for_backward(xbuf, work, *params)
         ctx.mod, ctx.geom, ctx.ogeom = mod, geom, _geom(out)
         return out.buf

@@ -25,6 +25,9 @@ struct RecArgs {
     int H, B, T;
     float* gsave;         // training: activated gates (i, f, g, o) written back over the pre-activations (same addressing as g)
     float* csave;         // training: cell state per step, [4 runs][T*B][H]
+    void* kimg;           // persistent bf16x3 recurrence only: K-major split image of h instead of hout (see lstm_pers.hip)
+    long long kimg_lo;
+    int Tp, Jp;
 };
 
 template <bool WREG>
@@ -584,8 +587,8 @@ int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
     if ((flags & 1) && !(flags & 8) && cstate && !ra.gsave && idv_lstm_pers_supported(ra.H, ra.B)) {
         // H = 384 / 768 (VAE encoders), split-bf16 mode: one persistent cooperative launch per layer (lstm_pers.hip);
         // its exchange buffer lives in the scratch behind cstate (idv_clstm_work_floats covers it: 4*H*Jp floats)
-        return idv_lstm_rec_pers(ra.g, ra.g_run_z, ra.g_run_s, ra.ldg, ra.whh, ra.hout, ra.H, ra.B, ra.T,
-                                 (void*)(cstate + 4LL * ra.B * ra.H), (void*)st);
+        return idv_lstm_rec_pers(ra.g, ra.g_run_z, ra.g_run_s, ra.ldg, ra.whh, ra.kimg ? nullptr : ra.hout, ra.H, ra.B, ra.T,
+                                 (void*)(cstate + 4LL * ra.B * ra.H), ra.kimg, ra.kimg_lo, ra.Tp, ra.Jp, (void*)st);
     }
     if (ra.H == 128 && (flags & 1)) {
         hipLaunchKernelGGL(lstm_rec_bf16_kernel, grid, dim3(256), 0, st, ra);
@@ -617,7 +620,7 @@ int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
 }  // namespace
 
 extern "C" long long idv_clstm_work_floats(int H, int B, int T, int Jp) {
-    return 24LL * T * B * H + 4LL * B * H + 4LL * H * Jp;
+    return 24LL * T * B * H + 4LL * B * H + 8LL * H * Jp;      // [G | h0 | h1 | cstate | hp / exchange | split image of h0]
 }
 // training (flags bit 2): both layers' gate buffers and the cell states are kept for the backward pass
 //   [G0 16TBH | G1 16TBH | h0 4TBH | h1 4TBH | c0 4TBH | c1 4TBH | cstate 4BH | hp 4*H*Jp]
@@ -627,7 +630,7 @@ extern "C" long long idv_clstm_train_work_floats(int H, int B, int T, int Jp) {
 
 extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
                              const float* wih1, const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp,
-                             float* work, float* out, int flags, void* stream) {
+                             float* work, float* out, int flags, const void* wih1_bf16, void* stream) {
     if (!x || !wih0 || !bih0 || !whh0 || !wih1 || !bih1 || !whh1 || !work || !out) return IDV_EINVAL;
     if (H <= 0 || (H % 16) || K <= 0 || (K & 1) || B <= 0 || T <= 0 || Tp < T + 1 || Jp < B * Tp) return IDV_EINVAL;
     if ((size_t)3 * H * 16 * sizeof(float) > 160 * 1024) return IDV_EINVAL;
@@ -650,16 +653,24 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
                          8 * H, stream);
         if (rc) return rc;
     }
-    RecArgs r0{G, TB * 8 * H, 4LL * H, 8 * H, whh0, h0, H, B, T, save ? G : nullptr, c0};
+    // split-bf16 mode with the persistent recurrence and bf16 fragments of W_ih1: layer 0 writes h0 as the K-major split
+    // image the bf16 point-wise kernel reads, no fp32 h0, no transpose (was: fp32 PW contraction, 14 % of the NSVAE step)
+    const bool img1 = (flags & 1) && !(flags & 8) && !save && wih1_bf16 && idv_lstm_pers_supported(H, B) &&
+                      idv_lstm_proj_bf16_supported(H, H) && (4 * H) % 256 == 0;
+    float* hp = cstate + 4LL * B * H;                  // [4 runs][H][Jp] (per-step path) / exchange buffer (persistent path)
+    void* himg = (void*)(hp + 4LL * H * Jp);           // [hi | lo][4 runs][H/8][Jp] x 16 B
+    const long long himg_lo = 4LL * (H / 8) * Jp;
+    RecArgs r0{G, TB * 8 * H, 4LL * H, 8 * H, whh0, h0, H, B, T, save ? G : nullptr, c0, img1 ? himg : nullptr, himg_lo, Tp, Jp};
     if ((rc = launch_rec(r0, cstate, flags, st))) return rc;
     // layer 1 input projection from h0 (row-major), per run
     const int KS = ((H + 7) / 8) * 4;
     dim3 ggrid((unsigned)((TB + 31) / 32), 4);
-    if (H == 128) {
+    if (img1) {
+        if ((rc = idv_lstm_proj1_bf16x3(himg, himg_lo, wih1_bf16, bih1, G1, H, B, T, Tp, Jp, stream))) return rc;
+    } else if (H == 128) {
         hipLaunchKernelGGL(gemm_rm_kernel<4>, ggrid, dim3(256), 0, st, h0, wih1, bih1, G1, H, TB, KS);
     } else if (H % 32 == 0) {
         // transpose h0 to planar and use the PW contraction: rows of weight set s start at tile s*(4H/32)
-        float* hp = cstate + 4LL * B * H;              // [4 runs][H][Jp]
         hipLaunchKernelGGL(lstm_to_planar_kernel, dim3((T + 31) / 32, (H + 31) / 32, 4 * B), dim3(256), 0, st, h0, H, B, T, Tp, Jp, hp);
         if ((rc = idv_launch_status())) return rc;
         for (int run = 0; run < 4; ++run) {
@@ -677,7 +688,7 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     }
     if ((rc = idv_launch_status())) return rc;
     // G1 is [run][TB][4H] with run = 2z + s
-    RecArgs r1{G1, 2 * TB * 4 * H, TB * 4 * H, 4 * H, whh1, h1, H, B, T, save ? G1 : nullptr, c1};
+    RecArgs r1{G1, 2 * TB * 4 * H, TB * 4 * H, 4 * H, whh1, h1, H, B, T, save ? G1 : nullptr, c1, nullptr, 0, Tp, Jp};
     if ((rc = launch_rec(r1, cstate, flags, st))) return rc;
     hipLaunchKernelGGL(lstm_combine_kernel, dim3((T + 31) / 32, (H + 31) / 32, B), dim3(256), 0, st, h1, H, B, T, Tp, Jp, out);
     const long long ntail = 2LL * H * B * (Tp - 1 - T);

@@ -30,7 +30,10 @@ struct PersArgs {
     long long g_run_z, g_run_s;
     int ldg;
     const uint4* whh16;       // split-bf16 fragments of idv_pack_lstm_hh: [set][tile = ub*4 + gate][kb][hi|lo][lane]
-    float* hout;              // [4 runs][T*B][H]
+    float* hout;              // [4 runs][T*B][H]  (nullptr: not wanted)
+    uint4* kimg;              // or nullptr: K-major split image of h_t, slot ((run * H/8 + octet) * Jp + b * Tp + t + 1)
+    long long kimg_lo;        //   hi -> lo distance in 16-byte slots
+    int Tp, Jp;
     unsigned short* hx;       // exchange [2 parity][4 runs][Bpad][H/8][hi 8 x bf16 | lo 8 x bf16]
     unsigned hx_bytes;
     unsigned* sync;           // [abort flag: 256 B][group = set * chunks + chunk][replica][256 B] arrive counters
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
             stage[rt][0][myrow][col] = __builtin_bit_cast(unsigned short, hh);
             stage[rt][1][myrow][col] = __builtin_bit_cast(unsigned short, hl);
             const int b = t_b0[rt] + myrow;
-            if (t_ok[rt] && b < a.B) a.hout[(size_t)t_run[rt] * TBH + ((size_t)t * a.B + b) * H + sl * 16 + col] = hv;
+            if (a.hout && t_ok[rt] && b < a.B) a.hout[(size_t)t_run[rt] * TBH + ((size_t)t * a.B + b) * H + sl * 16 + col] = hv;
         }
         __syncthreads();
         if (wave < NRT && t_ok[wave < NRT ? wave : 0]) {
@@ -242,6 +245,11 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
             const v4i pk = *(const v4i*)&stage[rt][sp][row][c8 * 8];
             const unsigned off = (((unsigned)t_run[rt] * a.Bpad + t_b0[rt] + row) * (unsigned)(H / 8) + sl * 2 + c8) * 32u + sp * 16u;
             __builtin_amdgcn_raw_buffer_store_b128(pk, hxr, off, par_w, 16);       // aux 16 = sc1
+            // the same 16 bytes are a slot of the K-major split image the next layer's input projection reads (plain store)
+            const int b = t_b0[rt] + row;
+            if (a.kimg && b < a.B)
+                a.kimg[(size_t)sp * a.kimg_lo + ((size_t)t_run[rt] * (H / 8) + sl * 2 + c8) * a.Jp + (size_t)b * a.Tp + t + 1] =
+                    __builtin_bit_cast(uint4, pk);
         }
         // ---- publish: every storing wave drains its stores, the workgroup meets, ONE wave instruction arrives
         IDV_STAMP(4)                                         // LDS reduction + cell update + stores issued
@@ -264,7 +272,10 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
                 const int u = (int)(e & 15), br = (int)((e >> 4) & 15);
                 const long long t = e >> 8;
                 const int b = t_b0[rt] + br;
-                if (b < a.B) a.hout[(size_t)t_run[rt] * TBH + ((size_t)t * a.B + b) * H + sl * 16 + u] = qnan;
+                if (b < a.B && a.hout) a.hout[(size_t)t_run[rt] * TBH + ((size_t)t * a.B + b) * H + sl * 16 + u] = qnan;
+                if (b < a.B && a.kimg && u < 2)      // hi halves of both octets: NaN bit patterns
+                    a.kimg[((size_t)t_run[rt] * (H / 8) + sl * 2 + u) * a.Jp + (size_t)b * a.Tp + t + 1] =
+                        make_uint4(0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u);
             }
         }
     }
@@ -308,13 +319,18 @@ static unsigned long long* g_prof = nullptr;
 // nullptr restores the production kernel.
 extern "C" void idv_lstm_pers_set_profile(unsigned long long* prof_cycles) { g_prof = prof_cycles; }
 
-// one layer of the recurrence; work: idv_lstm_pers_work_bytes(H, B) bytes (16-byte aligned), contents arbitrary
+// one layer of the recurrence; work: idv_lstm_pers_work_bytes(H, B) bytes (16-byte aligned), contents arbitrary.
+// Outputs, at least one: hout [4 runs][T*B][H] fp32 and / or kimg, the K-major split image of h (4 runs x H/8 octets x Jp
+// columns, column b*Tp + t + 1; kimg_lo_slots 16-byte slots from the hi to the lo plane) that idv_lstm_proj1_bf16x3 reads.
 extern "C" int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh_frag, float* hout,
-                                 int H, int B, int T, void* work, void* stream) {
+                                 int H, int B, int T, void* work, void* kimg, long long kimg_lo_slots, int Tp, int Jp,
+                                 void* stream) {
     using namespace idv_pers;
     unsigned long long* prof = g_prof;
-    if (!g || !whh_frag || !hout || !work || T <= 0 || !idv_lstm_pers_supported(H, B)) return IDV_EINVAL;
+    if (!g || !whh_frag || (!hout && !kimg) || !work || T <= 0 || !idv_lstm_pers_supported(H, B)) return IDV_EINVAL;
     if (reinterpret_cast<uintptr_t>(work) & 15) return IDV_EINVAL;
+    if (kimg && ((reinterpret_cast<uintptr_t>(kimg) & 15) || Tp < T + 1 || Jp < B * Tp || kimg_lo_slots < 4LL * (H / 8) * Jp))
+        return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nrt = nrt_for(H, B);
     const int TPR = (B + 15) / 16, NT = 2 * TPR;
@@ -333,6 +349,7 @@ extern "C" int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_
     a.g = g; a.g_run_z = g_run_z; a.g_run_s = g_run_s; a.ldg = ldg;
     a.whh16 = (const uint4*)(whh_frag + (size_t)2 * 4 * H * H);
     a.hout = hout;
+    a.kimg = (uint4*)kimg; a.kimg_lo = kimg_lo_slots; a.Tp = Tp; a.Jp = Jp;
     a.sync = (unsigned*)work;
     a.hx = (unsigned short*)((char*)work + SYNC_BYTES);
     a.hx_bytes = (unsigned)hx_bytes;

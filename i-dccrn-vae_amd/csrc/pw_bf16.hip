@@ -319,6 +319,33 @@ extern "C" int idv_lstm_proj_bf16x3(const void* ximg, long long lo_off_slots, in
     return eff(64) > eff(128) + 0.02 ? launch_pw<2, 2, true>(a, st) : launch_pw<4, 2, true>(a, st);
 }
 
+// Layer-1 input projection of the complex LSTM from the K-major split image of h0 that idv_lstm_rec_pers wrote (4 runs x
+// H/8 octets): G1[run = 2z + s][(t, b)][4H] = W_ih1(set s) h0[run] + bias.  wfrag_bf16: idv_pack_lstm_ih_bf16(w_ih_l1 of
+// both sets, H, K = H); bias: [2 sets][4H] in the recurrence's gate-column order (idv_pack_lstm_ih).
+extern "C" int idv_lstm_proj1_bf16x3(const void* himg, long long lo_off_slots, const void* wfrag_bf16, const float* bias, float* G1,
+                                     int H, int B, int T, int Tp, int Jp, void* stream) {
+    if (!himg || !wfrag_bf16 || !bias || !G1 || !idv_lstm_proj_bf16_supported(H, H) || (4 * H) % 256 || B <= 0 || T <= 0 ||
+        Tp < T + 1 || Jp < B * Tp)
+        return IDV_EINVAL;
+    if (reinterpret_cast<uintptr_t>(himg) & 15) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int KO = H / 8;
+    for (int s = 0; s < 2; ++s) {
+        PwBf16Args a{};
+        a.ximg = (const u32x4*)himg + (long long)s * KO * Jp;       // runs s and 2 + s are this weight set's two parts
+        a.lo_off = lo_off_slots; a.KO = KO; a.part_stride = 2LL * KO * Jp;
+        a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.t_valid = T; a.nB = B;
+        a.wfrag = (const uint4*)wfrag_bf16 + (long long)s * (4 * H / 32) * (H / 16) * 2 * 64;
+        a.bias = bias + s * 4 * H; a.out = G1 + (long long)s * T * B * 4 * H;
+        a.out_part_stride = 2LL * T * B * 4 * H; a.ldo = 4 * H; a.M = 4 * H;
+        const long long mb = (a.M + 255) / 256;
+        auto eff = [&](int jt) { const long long n = ((a.J + jt - 1) / jt) * mb; return (double)n / (double)(((n + 255) / 256) * 256); };
+        const int rc = eff(64) > eff(128) + 0.02 ? launch_pw<2, 2, true>(a, st) : launch_pw<4, 2, true>(a, st);
+        if (rc) return rc;
+    }
+    return IDV_OK;
+}
+
 namespace {
 
 // generic [M][K] row-major fp32 -> fragments, K zero-padded to Kp (a multiple of 64), rows padded to 256

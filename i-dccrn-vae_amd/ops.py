@@ -446,7 +446,7 @@ def pack_lstm(sd_get, H: int, K: int, layer: int, device):
     whh = torch.empty(4 * 4 * H * H, dtype=torch.float32, device=device)
     call("idv_pack_lstm_hh", p(g(f"lstm_re.weight_hh_l{l}")), p(g(f"lstm_im.weight_hh_l{l}")), i(H), p(whh), stream_ptr())
     wih16 = None
-    if layer == 0 and L.lib().idv_lstm_proj_bf16_supported(i(H), i(K)):
+    if L.lib().idv_lstm_proj_bf16_supported(i(H), i(K)) and (layer == 0 or (4 * H) % 256 == 0):
         L.lib().idv_lstm_ih_bf16_bytes.restype = L._L
         wih16 = torch.empty(int(L.lib().idv_lstm_ih_bf16_bytes(i(H), i(K))), dtype=torch.uint8, device=device)
         call("idv_pack_lstm_ih_bf16", p(g(f"lstm_re.weight_ih_l{l}")), p(g(f"lstm_im.weight_ih_l{l}")), i(H), i(K), p(wih16),
@@ -475,7 +475,8 @@ def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
              i(x.T), i(x.Tp), i(x.Jp), stream_ptr())
         flags |= 2
     call("idv_clstm_fwd", x.ptr(), i(K), p(packed0[0]), p(packed0[1]), p(packed0[2]), p(packed1[0]), p(packed1[1]),
-         p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), i(flags), stream_ptr())
+         p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), i(flags),
+         p(packed1[3] if (flags & 1) else None), stream_ptr())
     return out
 
 

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IDV_ABI_VERSION 2
+#define IDV_ABI_VERSION 3
 #define IDV_SLACK_FLOATS 256
 
 int idv_abi_version(void);
@@ -182,17 +182,25 @@ int idv_planar_to_complex(const float* act, float* out_c, int F, int B, int T, i
 /* ComplexLSTM.forward (complex_progress.py:50-74): four 2-layer LSTM passes, real = rr - ii,
  * imag = ir + ri.  x: planar [2][K][Jp]; out: planar [2][H][Jp].  flags bit 0: split-bf16 recurrence (H = 128).  wihN / bihN: idv_pack_lstm_ih of layer
  * N, whhN: idv_pack_lstm_hh of layer N.  work: idv_clstm_work_floats(H, B, T, Jp) floats. */
-long long idv_clstm_work_floats(int H, int B, int T, int Jp);   /* 24*T*B*H + 4*B*H + 4*H*Jp */
+long long idv_clstm_work_floats(int H, int B, int T, int Jp);   /* 24*T*B*H + 4*B*H + 8*H*Jp */
 /* Persistent cooperative recurrence of one layer for H = 384 / 768 (the VAE encoders' 3*zdim / 6*zdim, reference
  * model/pvae_module.py:1819, :2160-2163), split-bf16 arithmetic: H/16 co-resident workgroups per weight set keep their
- * W_hh slice in registers for all T steps and exchange h_t through global memory with a per-step arrive counter (bounded
- * spins; on a time-out the outputs are NaN).  idv_clstm_fwd uses it when flags bit 0 is set and idv_lstm_pers_supported;
- * flags bit 3 forces the per-step kernel.  g / g_run_z / g_run_s / ldg address the gate pre-activations as G0 / G1 below,
- * whh_frag: idv_pack_lstm_hh, hout: [4 runs][T*B][H], work: idv_lstm_pers_work_bytes(H, B) bytes, 16-byte aligned. */
+ * W_hh slice in registers for all T steps and exchange h_t through global memory (write-through stores, one arrive
+ * counter per group of workgroups, no cache-wide fences; bounded spins; on a time-out the outputs are NaN).  idv_clstm_fwd
+ * uses it when flags bit 0 is set and idv_lstm_pers_supported; flags bit 3 forces the per-step kernel.  g / g_run_z /
+ * g_run_s / ldg address the gate pre-activations as G0 / G1 below, whh_frag: idv_pack_lstm_hh, work:
+ * idv_lstm_pers_work_bytes(H, B) bytes, 16-byte aligned.  Outputs (at least one): hout [4 runs][T*B][H] fp32; kimg, the
+ * K-major split image of h (slot ((run * H/8 + octet) * Jp + b*Tp + t + 1), lo plane kimg_lo_slots 16-byte slots behind
+ * the hi plane) that idv_lstm_proj1_bf16x3 consumes. */
 int idv_lstm_pers_supported(int H, int B);
 long long idv_lstm_pers_work_bytes(int H, int B);
 int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh_frag, float* hout, int H,
-                      int B, int T, void* work, void* stream);
+                      int B, int T, void* work, void* kimg, long long kimg_lo_slots, int Tp, int Jp, void* stream);
+/* Layer-1 input projection (nn.LSTM weight_ih_l1 of lstm_re / lstm_im, complex_progress.py:50-74) in split-bf16 from that
+ * image: G1[run = 2z + s][(t, b)][4H].  wfrag_bf16: idv_pack_lstm_ih_bf16(w_ih_l1 re, im, H, K = H); bias: bih1 of
+ * idv_pack_lstm_ih.  Needs 4H % 256 == 0 and H % 64 == 0. */
+int idv_lstm_proj1_bf16x3(const void* himg, long long lo_off_slots, const void* wfrag_bf16, const float* bias, float* G1, int H,
+                          int B, int T, int Tp, int Jp, void* stream);
 /* diagnostic (not part of the drop-in boundary): while a device buffer of 256 x 8 counters is registered, idv_lstm_rec_pers runs
  * an instrumented twin in which every workgroup accumulates core-clock cycles per phase (spin, -, barrier, loads + MFMA,
  * reduce + cell, drain + barrier, -, XCC id); NULL restores the production kernel.  tests/tools/lstm_phase_probe.py */
@@ -203,9 +211,11 @@ void idv_lstm_pers_set_profile(unsigned long long* prof_cycles);
  * G0: [z][T*B][8H] (z = real / imag input; columns [weight set s][4H]), G1: [run = 2z+s][T*B][4H], h/c: [run][T*B][H];
  * gate columns are ordered colp = ((u/16)*4 + gate)*16 + u%16. */
 long long idv_clstm_train_work_floats(int H, int B, int T, int Jp);   /* 48*T*B*H + 4*B*H + 4*H*Jp */
+/* wih1_bf16 (may be NULL): idv_pack_lstm_ih_bf16 of layer 1; with it, flags bit 0 and the persistent recurrence, layer 0
+ * hands h0 to the layer-1 projection as a split image (idv_lstm_proj1_bf16x3) instead of fp32 rows. */
 int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0, const float* wih1,
                   const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp, float* work, float* out,
-                  int flags, void* stream);
+                  int flags, const void* wih1_bf16, void* stream);
 
 /* Split-precision (bf16x3) form of the layer-0 input projection inside idv_clstm_fwd (nn.LSTM weight_ih_l0 of
  * lstm_re / lstm_im applied to the real / imaginary input, complex_progress.py:50-74): ximg = K-major split image of
