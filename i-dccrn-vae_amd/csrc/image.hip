@@ -8,8 +8,10 @@
 namespace {
 
 // one thread: one (octet, f, j) slot = 8 planes
+// rep > 1: every utterance (Tp columns) of x appears rep times in a row in the image (skip.repeat_interleave(rep, 0) of the
+// two-phase decoder, reference pvae_module.py:2563-2567, fused into the conversion); x then has J / rep columns, pitch Jp_in
 __global__ void planar_to_image_kernel(const float* __restrict__ x, int C, int F, int J, int Jp, unsigned short* __restrict__ img,
-                                       long long lo_off) {
+                                       long long lo_off, int Tp, int rep, int Jp_in) {
     const long long n = (long long)((2 * C + 7) / 8) * F * Jp;
     if (blockIdx.x == 0 && threadIdx.x < 2)
         *(uint4*)(img + IDV_IMG_ZSLOT * 8 + (threadIdx.x ? lo_off : 0)) = make_uint4(0u, 0u, 0u, 0u);
@@ -23,8 +25,13 @@ __global__ void planar_to_image_kernel(const float* __restrict__ x, int C, int F
             const int ci = 4 * o + w;
             float x0 = 0.f, x1 = 0.f;
             if (ci < C && j < J) {
-                x0 = x[((size_t)ci * F + f) * Jp + j];
-                x1 = x[((size_t)(C + ci) * F + f) * Jp + j];
+                int jin = j;
+                if (rep > 1) {
+                    const int bo = j / Tp;
+                    jin = (bo / rep) * Tp + (j - bo * Tp);
+                }
+                x0 = x[((size_t)ci * F + f) * Jp_in + jin];
+                x1 = x[((size_t)(C + ci) * F + f) * Jp_in + jin];
             }
             const unsigned u0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u;
             const unsigned u1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
@@ -66,7 +73,22 @@ extern "C" int idv_planar_to_image(const float* x, int C, int F, int J, int Jp, 
     long long g = (n + 255) / 256;
     if (g > 65536) g = 65536;
     hipLaunchKernelGGL(planar_to_image_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, C, F, J, Jp,
-                       (unsigned short*)img, lo_off);
+                       (unsigned short*)img, lo_off, J, 1, Jp);
+    return idv_launch_status();
+}
+
+// planar [2][C][F][Jp_in] with B utterances of Tp columns -> split image with B * rep utterances, each input utterance rep times
+// in a row (pitch Jp >= B * rep * Tp)
+extern "C" int idv_planar_to_image_repeat(const float* x, int C, int F, int B, int Tp, int Jp_in, int rep, void* img, long long lo_off,
+                                          int Jp, void* stream) {
+    if (!x || !img || C <= 0 || F <= 0 || B <= 0 || Tp <= 1 || rep <= 0 || Jp_in < B * Tp || Jp < (long long)B * rep * Tp || (lo_off % 8) ||
+        (reinterpret_cast<uintptr_t>(img) & 15))
+        return IDV_EINVAL;
+    const long long n = (long long)((2 * C + 7) / 8) * F * Jp;
+    long long g = (n + 255) / 256;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(planar_to_image_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, C, F, B * rep * Tp, Jp,
+                       (unsigned short*)img, lo_off, Tp, rep, Jp_in);
     return idv_launch_status();
 }
 

@@ -525,7 +525,11 @@ class _VAEDecoderBase(nn.Module):
                     if Bn % sk.B:
                         raise RuntimeError("batch of z is not a multiple of the skip batch")
                     if Bn != sk.B:
-                        sk = ops.repeat_batch(sk, Bn // sk.B)
+                        # behind a block that handed over an image the skip is lifted anyway: repeat inside that conversion
+                        if isinstance(p, ops.Image) and dec.transconv.takes_images(p.C, sk.C):
+                            sk = ops.to_image_repeat(sk, Bn // sk.B)
+                        else:
+                            sk = ops.repeat_batch(sk, Bn // sk.B)
                 nxt = self.decoders[i + 1].transconv if i + 1 < nd else None
                 c_out = dec.transconv.out_channel
                 nxt_skip = 0

@@ -130,6 +130,14 @@ def to_image(x: Planar) -> Image:
     return out
 
 
+def to_image_repeat(x: Planar, n: int) -> Image:
+    """to_image(repeat_batch(x, n)) in one pass: each utterance n times in a row, straight into the split image."""
+    out = Image.empty(x.C, x.F, x.B * n, x.T, x.Tp, x.buf.device)
+    call("idv_planar_to_image_repeat", x.ptr(), i(x.C), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(n), out.ptr(), ll(out.lo_off),
+         i(out.Jp), stream_ptr())
+    return out
+
+
 def to_planar(x: Image) -> Planar:
     out = Planar.empty(x.C, x.F, x.B, x.T, x.Tp, x.buf.device)
     call("idv_image_to_planar", x.ptr(), ll(x.lo_off), i(x.C), i(x.F), i(x.B * x.Tp), i(x.Jp), out.ptr(), stream_ptr())

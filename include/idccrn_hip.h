@@ -116,6 +116,10 @@ int idv_cconv2d_fwd_img(const float* x0, int C0, const float* x1, int C1, int Jp
 int idv_cconv_img_config(int src_is_image, int transposed, int Cin, int Cout, int Fin);   /* template digits <MODE, WM, WN,
                         FO_T, JC_W, MT_W, IMGIN, AD> of the cgemm_bf16_kernel idv_cconv2d_img_fwd launches (profiles) */
 int idv_planar_to_image(const float* x, int C, int F, int J, int Jp, void* img, long long lo_off_elems, void* stream);
+/* the same with every utterance repeated rep times in a row (skip.repeat_interleave(num_samples, 0) of the two-phase decoder,
+ * pvae_module.py:2563-2567, fused into the conversion): x has B utterances (pitch Jp_in), the image B * rep (pitch Jp) */
+int idv_planar_to_image_repeat(const float* x, int C, int F, int B, int Tp, int Jp_in, int rep, void* img, long long lo_off_elems,
+                               int Jp, void* stream);
 int idv_image_to_planar(const void* img, long long lo_off_elems, int C, int F, int J, int Jp, float* x, void* stream);
 int idv_cconv2d_img_fwd(int src_is_image /* 0: x0/x1 are planar fp32 (row stride Jp) */, const void* x0_img, long long lo_off0_slots, int C0, const void* x1_img, long long lo_off1_slots,
                         int C1, const void* wfrag_bf16, const float* bias, const float* prelu_slope, float* out_planar,
