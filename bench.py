@@ -267,6 +267,8 @@ TRAIN_WORKLOADS = ("dccrn_cl_train", "cvae_train", "nsvae_train", "twophase_trai
 def kernel_name(cfg_id):
     if cfg_id == -97:
         return "void (anonymous namespace)::wgrad_kernel<5, 2, 1, 1, 4, 1, 16, 2>(WgradArgs) + wgrad_unpack_conv_kernel"
+    if cfg_id == -96:
+        return "void (anonymous namespace)::wgrad_bf16_kernel(WgradArgs) + wgrad_unpack_conv_kernel"
     if cfg_id in (-99, -98):
         return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
     if cfg_id > 0:

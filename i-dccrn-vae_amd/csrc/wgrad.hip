@@ -17,21 +17,11 @@
 // adjacent columns: lanes 0-31 read LDS column c, lanes 32-63 column c+1, so the time tap is a free column
 // offset and all LDS reads are conflict free (odd row and plane pitches against the 32 banks of ds_read_b32).
 #include "common.hpp"
+#include "wgrad_common.hpp"
 #include "../../include/idccrn_hip.h"
 
 namespace {
 
-struct WgradArgs {
-    const float* S;      // planar [Sp][Fs][JpS]
-    const float* L;      // planar [Lp][Fl][JpL]
-    int Sp, Lp, Fs, Fl;
-    int J, JpS, JpL;
-    int dt0;             // L column = S column + kt + dt0
-    float* part;         // [nsplit][TAPS][SpPad][LpPad]
-    int SpPad, LpPad;
-    int jtiles;          // ceil(J / WG_JT)
-    int jt_per_split;
-};
 
 // WG_JT columns per step; LDS row pitch WG_JT + 3 words: odd, so the 32 planes one 32-lane half reads with ds_read_b32
 // (bank = word address % 32, lanes l and l+32 never conflict) land on 32 distinct banks, for the S tile (plane pitch =
@@ -282,31 +272,14 @@ __global__ void cconv_bias_grad_kernel(const double* __restrict__ stats, int Cou
 constexpr int CONV_JT = 16, PW_JT = 32;
 constexpr int CONV_MS = 128, CONV_ML = 32;      // wgrad_kernel<5, 2, 1, 1, 4, 1, ...>: 4 x 1 waves of one 32 x 32 tile x 10 taps
 
-struct Plan { int tilesS, tilesL, nsplit, jtiles, jt_per_split, SpPad, LpPad; };
-
-inline Plan make_plan(int Sp, int Lp, int J, int MS, int ML, int JT) {
-    Plan p;
-    p.tilesS = (Sp + MS - 1) / MS;
-    p.tilesL = (Lp + ML - 1) / ML;
-    p.SpPad = p.tilesS * MS;
-    p.LpPad = p.tilesL * ML;
-    p.jtiles = (J + JT - 1) / JT;
-    int want = (1024 + p.tilesS * p.tilesL - 1) / (p.tilesS * p.tilesL);
-    if (want < 1) want = 1;
-    if (want > p.jtiles) want = p.jtiles;
-    p.jt_per_split = (p.jtiles + want - 1) / want;
-    p.nsplit = (p.jtiles + p.jt_per_split - 1) / p.jt_per_split;
-    return p;
-}
-
-inline int grid_for(long long n) {
-    long long g = (n + 255) / 256;
-    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
-}
-
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+void launch_wgrad_unpack_conv(const float* part, int nsplit, int SpPad, int LpPad, int Cout, int Cx, int Cin_total, int ci_off,
+                              int transposed, float* dw_re, float* dw_im, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_unpack_conv_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, part, nsplit, SpPad,
+                       LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
+}
 
 extern "C" long long idv_cconv_wgrad_work_floats(int Cs, int Cl, int B, int Tp) {
     if (Cs <= 0 || Cl <= 0 || B <= 0 || Tp <= 0) return -1;

@@ -1,0 +1,247 @@
+// Weight gradient of the complex conv / transposed conv blocks in split-bf16 ("bf16x3") arithmetic: the contraction of
+// wgrad.hip (same operands, same split-K partial tiles, same unpack kernel)
+//
+//   G[kf][kt][sp][lp] = sum_{fs, j} S[sp][fs][j] * L[lp][2*fs + kf - 2][j + kt + dt0]
+//
+// on v_mfma_f32_32x32x16_bf16 with both operands split on the fly, x = hi + lo (hi = the fp32 value truncated to bf16,
+// lo = bf16(x - hi)), S*L ~ S_hi*L_hi + S_hi*L_lo + S_lo*L_hi, fp32 accumulate: 5.3x fewer MFMA cycles than the exact
+// fp32 32x32x2 form.  What autograd computes for nn.Conv2d / nn.ConvTranspose2d weights behind `loss.backward()`
+// (reference model/complex_progress.py:8-36, :222-279; train steps supervised_dccrn/train.py:239-243 etc.).
+//
+// The MFMA k index is the COLUMN j: a lane holds 8 consecutive columns of its plane (one ds_read_b128).  A time tap is a
+// column offset of one, which would misalign that read by 2 bytes, so the L tile is staged twice: aligned and shifted by
+// one column (the shift is made in registers from the aligned float4 + the neighbour lane's edge element).  The four waves
+// are (2 halves of the 128 S planes) x (2 time taps): a wave holds 2 x 5 accumulator tiles (64 S planes x 32 L planes x 5
+// frequency taps) and reads 14 LDS fragments per 30 MFMAs.
+#include "common.hpp"
+#include "bf16_common.hpp"
+#include "wgrad_common.hpp"
+#include "../../include/idccrn_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int BW_MS = 128, BW_ML = 32, BW_JT = 32, BW_KF = 5;
+constexpr int BW_PITCH = BW_JT + 8;                 // bf16 elements per LDS row: 80 bytes = 5 x 16 (odd): conflict-free b128 reads
+constexpr int BW_LROWS = BW_ML * BW_KF;             // 160
+
+__device__ __forceinline__ void split4(const f32x4 v, const bool (&ok)[4], uint2& hi, uint2& lo) {
+    unsigned h[4];
+    float r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float x = ok[c] ? v[c] : 0.f;
+        h[c] = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+        r[c] = x - __builtin_bit_cast(float, h[c]);
+    }
+    hi = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+    lo = make_uint2(pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3]));
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
+    constexpr int Q4 = BW_JT / 4;                                       // float4 slots per row
+    constexpr int NS4 = BW_MS * Q4 / 256, NL4 = BW_LROWS * Q4 / 256;    // 4, 5
+    __shared__ __attribute__((aligned(16))) unsigned short Ssm[2][BW_MS][BW_PITCH];          // [hi|lo]
+    __shared__ __attribute__((aligned(16))) unsigned short Lsm[2][2][BW_LROWS][BW_PITCH];    // [aligned|shifted][hi|lo]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wt = wave & 1;                 // S half, time tap
+    const int half = lane >> 5, l31 = lane & 31;
+    const int split = blockIdx.x, ts = blockIdx.y, tl = blockIdx.z;
+    const int sp0 = ts * BW_MS, lp0 = tl * BW_ML;
+    const int jt0 = split * a.jt_per_split;
+    int jt1 = jt0 + a.jt_per_split;
+    if (jt1 > a.jtiles) jt1 = a.jtiles;
+    const int nsteps = (jt1 > jt0) ? (jt1 - jt0) * a.Fs : 0;
+    // L column = S column + kt + dt0: the aligned copy serves kt + dt0 == 0, the copy shifted by d = (dt0 == 0 ? +1 : -1)
+    // the other tap
+    const int d = a.dt0 == 0 ? 1 : -1;
+    const int my_copy = (wt + a.dt0 == 0) ? 0 : 1;
+
+    f32x16 acc[2][BW_KF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < BW_KF; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+    f32x4 sreg[NS4], lreg[NL4];
+    float hreg[NL4];
+
+    // Branch-free staging (see wgrad.hip): every slot loads unconditionally, invalid slots read element 0; the masks are
+    // applied when the registers are split and written to LDS one step later.
+    auto load_step = [&](int step) {
+        const int jt = jt0 + step / a.Fs, fs = step - (step / a.Fs) * a.Fs;
+        const int j0 = jt * BW_JT;
+#pragma unroll
+        for (int i = 0; i < NS4; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int sp = sp0 + row, j = j0 + 4 * q;
+            const bool ok = (sp < a.Sp) && (j < a.J);
+            const size_t off = ok ? ((size_t)sp * a.Fs + fs) * a.JpS + j : 0;
+            sreg[i] = *(const f32x4*)(a.S + off);
+        }
+#pragma unroll
+        for (int i = 0; i < NL4; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int pl = row / BW_KF, kf = row - pl * BW_KF;
+            const int lp = lp0 + pl, fl = 2 * fs + kf - 2, j = j0 + 4 * q;
+            const bool rok = (lp < a.Lp) && (fl >= 0) && (fl < a.Fl);
+            const size_t base = rok ? ((size_t)lp * a.Fl + fl) * a.JpL : 0;
+            lreg[i] = *(const f32x4*)(a.L + base + ((rok && j < a.J) ? j : 0));
+            // edge element of the shifted copy: column j0 + 32 (d = +1, slot q = 7) or j0 - 1 (d = -1, slot q = 0)
+            const int je = d > 0 ? j0 + BW_JT : j0 - 1;
+            hreg[i] = a.L[base + ((rok && je >= 0 && je < a.J) ? je : 0)];
+        }
+    };
+    auto store_step = [&](int step) {
+        const int jt = jt0 + step / a.Fs, fs = step - (step / a.Fs) * a.Fs;
+        const int j0 = jt * BW_JT;
+#pragma unroll
+        for (int i = 0; i < NS4; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int sp = sp0 + row, j = j0 + 4 * q;
+            bool ok[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ok[c] = (sp < a.Sp) && (j + c < a.J);
+            uint2 hi, lo;
+            split4(sreg[i], ok, hi, lo);
+            *(uint2*)&Ssm[0][row][4 * q] = hi;
+            *(uint2*)&Ssm[1][row][4 * q] = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NL4; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int pl = row / BW_KF, kf = row - pl * BW_KF;
+            const int lp = lp0 + pl, fl = 2 * fs + kf - 2, j = j0 + 4 * q;
+            const bool rok = (lp < a.Lp) && (fl >= 0) && (fl < a.Fl);
+            // aligned copy: columns j .. j+3
+            f32x4 v = lreg[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (rok && j + c < a.J) ? v[c] : 0.f;
+            // shifted copy: columns j+d .. j+d+3 = own elements + the neighbour slot's edge element (lanes e +- 1 hold the
+            // neighbouring float4 of the same row; at the row ends the separately loaded edge element)
+            const int je = d > 0 ? j0 + BW_JT : j0 - 1;
+            const float edge = (rok && je >= 0 && je < a.J) ? hreg[i] : 0.f;
+            const float nb = d > 0 ? __shfl_down(v[0], 1) : __shfl_up(v[3], 1);
+            f32x4 w;
+            if (d > 0) {
+                w[0] = v[1]; w[1] = v[2]; w[2] = v[3]; w[3] = (q == Q4 - 1) ? edge : nb;
+            } else {
+                w[0] = (q == 0) ? edge : nb; w[1] = v[0]; w[2] = v[1]; w[3] = v[2];
+            }
+            const bool all[4] = {true, true, true, true};
+            uint2 hi, lo;
+            split4(v, all, hi, lo);
+            *(uint2*)&Lsm[0][0][row][4 * q] = hi;
+            *(uint2*)&Lsm[0][1][row][4 * q] = lo;
+            split4(w, all, hi, lo);
+            *(uint2*)&Lsm[1][0][row][4 * q] = hi;
+            *(uint2*)&Lsm[1][1][row][4 * q] = lo;
+        }
+    };
+
+    if (nsteps > 0) load_step(0);
+    for (int step = 0; step < nsteps; ++step) {
+        store_step(step);
+        __syncthreads();
+        if (step + 1 < nsteps) load_step(step + 1);      // global loads fly under this step's MFMAs
+        const unsigned short* Ah = &Ssm[0][wm * 64 + l31][half * 8];
+        const unsigned short* Al = &Ssm[1][wm * 64 + l31][half * 8];
+        const unsigned short* Bh = &Lsm[my_copy][0][l31 * BW_KF][half * 8];
+        const unsigned short* Bl = &Lsm[my_copy][1][l31 * BW_KF][half * 8];
+        // B fragments one (kc, kf) ahead of their MFMAs (explicit double buffer: 16 instead of 40 registers)
+        bf16x8_t ah[2], al[2], bh[2], bl[2];
+        bh[0] = *(const bf16x8_t*)(Bh);
+        bl[0] = *(const bf16x8_t*)(Bl);
+#pragma unroll
+        for (int kc = 0; kc < BW_JT / 16; ++kc) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *(const bf16x8_t*)(Ah + i * 32 * BW_PITCH + kc * 16);
+                al[i] = *(const bf16x8_t*)(Al + i * 32 * BW_PITCH + kc * 16);
+            }
+#pragma unroll
+            for (int k = 0; k < BW_KF; ++k) {
+                const int cur = (kc * BW_KF + k) & 1, nxt = cur ^ 1;
+                const int nk = (k + 1 < BW_KF) ? k + 1 : 0, nkc = (k + 1 < BW_KF) ? kc : kc + 1;
+                if (nkc < BW_JT / 16) {
+                    bh[nxt] = *(const bf16x8_t*)(Bh + nk * BW_PITCH + nkc * 16);
+                    bl[nxt] = *(const bf16x8_t*)(Bl + nk * BW_PITCH + nkc * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x16 c = acc[i][k];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[cur], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[cur], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[cur], c, 0, 0, 0);
+                    acc[i][k] = c;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // partial tile -> workspace (every slot of the padded tile is written, so the workspace needs no clearing)
+    float* P = a.part + (size_t)split * 10 * a.SpPad * a.LpPad;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < BW_KF; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int sp = sp0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int lp = lp0 + l31;
+                P[((size_t)(k * 2 + wt) * a.SpPad + sp) * a.LpPad + lp] = acc[i][k][r];
+            }
+}
+
+}  // namespace
+
+extern "C" long long idv_cconv_wgrad_bf16_work_floats(int Cs, int Cl, int B, int Tp) {
+    if (Cs <= 0 || Cl <= 0 || B <= 0 || Tp <= 0) return -1;
+    const Plan p = make_plan(2 * Cs, 2 * Cl, B * Tp, BW_MS, BW_ML, BW_JT);
+    return (long long)p.nsplit * 10 * p.SpPad * p.LpPad;
+}
+
+// idv_cconv2d_bwd_weight in split-bf16 arithmetic (bf16x3 training mode); arguments as there, work:
+// idv_cconv_wgrad_bf16_work_floats(Cs, Cl, B, Tp) floats with (Cs, Cl) = (Cout, Cx) for the conv, (Cx, Cout) transposed
+extern "C" int idv_cconv2d_bwd_weight_bf16x3(const float* x, int Cx, int ci_off, const float* dy, int Cout, int Cin_total,
+                                             int transposed, int tshift, int Fin, int B, int Tp, int Jp_x, int Jp_dy, float* work,
+                                             long long work_floats, float* dw_re, float* dw_im, void* stream) {
+    if (!x || !dy || !work || !dw_re || !dw_im || Cx <= 0 || Cout <= 0 || ci_off < 0 || ci_off + Cx > Cin_total || Fin <= 0 ||
+        B <= 0 || Tp <= 1)
+        return IDV_EINVAL;
+    if ((tshift != 0 && tshift != -1) || (Jp_x % 4) || (Jp_dy % 4) || !aligned16(x) || !aligned16(dy) || Jp_x < B * Tp ||
+        Jp_dy < B * Tp)
+        return IDV_EINVAL;
+    const int Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
+    WgradArgs a{};
+    if (!transposed) {      // S = dy [2Cout][Fout], L = x [2Cx][Fin]
+        if (2 * Fout - 1 != Fin) return IDV_EINVAL;
+        a.S = dy; a.Sp = 2 * Cout; a.Fs = Fout; a.JpS = Jp_dy;
+        a.L = x;  a.Lp = 2 * Cx;   a.Fl = Fin;  a.JpL = Jp_x;
+        a.dt0 = tshift;
+    } else {                // S = x [2Cx][Fin], L = dy [2Cout][Fout]
+        a.S = x;  a.Sp = 2 * Cx;   a.Fs = Fin;  a.JpS = Jp_x;
+        a.L = dy; a.Lp = 2 * Cout; a.Fl = Fout; a.JpL = Jp_dy;
+        a.dt0 = 0;
+    }
+    a.J = B * Tp;
+    const Plan p = make_plan(a.Sp, a.Lp, a.J, BW_MS, BW_ML, BW_JT);
+    if ((long long)p.nsplit * 10 * p.SpPad * p.LpPad > work_floats) return IDV_EINVAL;
+    a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles; a.jt_per_split = p.jt_per_split;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
+    launch_wgrad_unpack_conv(work, p.nsplit, p.SpPad, p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im, st);
+    return idv_launch_status();
+}

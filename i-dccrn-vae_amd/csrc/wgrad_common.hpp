@@ -1,0 +1,49 @@
+// Shared by wgrad.hip (exact fp32) and wgrad_bf16.hip (split-bf16): the argument block of the weight-gradient contraction,
+// the split-K plan and the launcher of the deterministic unpack kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace {
+
+struct WgradArgs {
+    const float* S;      // planar [Sp][Fs][JpS]
+    const float* L;      // planar [Lp][Fl][JpL]
+    int Sp, Lp, Fs, Fl;
+    int J, JpS, JpL;
+    int dt0;             // L column = S column + kt + dt0
+    float* part;         // [nsplit][TAPS][SpPad][LpPad]
+    int SpPad, LpPad;
+    int jtiles;          // ceil(J / WG_JT)
+    int jt_per_split;
+};
+
+struct Plan { int tilesS, tilesL, nsplit, jtiles, jt_per_split, SpPad, LpPad; };
+
+inline Plan make_plan(int Sp, int Lp, int J, int MS, int ML, int JT) {
+    Plan p;
+    p.tilesS = (Sp + MS - 1) / MS;
+    p.tilesL = (Lp + ML - 1) / ML;
+    p.SpPad = p.tilesS * MS;
+    p.LpPad = p.tilesL * ML;
+    p.jtiles = (J + JT - 1) / JT;
+    int want = (1024 + p.tilesS * p.tilesL - 1) / (p.tilesS * p.tilesL);
+    if (want < 1) want = 1;
+    if (want > p.jtiles) want = p.jtiles;
+    p.jt_per_split = (p.jtiles + want - 1) / want;
+    p.nsplit = (p.jtiles + p.jt_per_split - 1) / p.jt_per_split;
+    return p;
+}
+
+inline int grid_for(long long n) {
+    long long g = (n + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// sums the split-K partial tiles in a fixed order and folds the four real products of a complex pair into (dW_re, dW_im)
+void launch_wgrad_unpack_conv(const float* part, int nsplit, int SpPad, int LpPad, int Cout, int Cx, int Cin_total, int ci_off,
+                              int transposed, float* dw_re, float* dw_im, hipStream_t st);

@@ -306,6 +306,12 @@ long long idv_cconv_wgrad_work_floats(int Cs, int Cl, int B, int Tp);
 int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const float* dy, int Cout, int Cin_total, int transposed,
                            int tshift, int Fin, int B, int Tp, int Jp_x, int Jp_dy, float* work, long long work_floats,
                            float* dw_re, float* dw_im, void* stream);
+/* the same contraction in split-bf16 arithmetic (both operands split on the fly, three v_mfma_f32_32x32x16_bf16 per product
+ * block, fp32 accumulate): the weight gradient of the bf16x3 training mode; work: idv_cconv_wgrad_bf16_work_floats */
+long long idv_cconv_wgrad_bf16_work_floats(int Cs, int Cl, int B, int Tp);
+int idv_cconv2d_bwd_weight_bf16x3(const float* x, int Cx, int ci_off, const float* dy, int Cout, int Cin_total, int transposed,
+                                  int tshift, int Fin, int B, int Tp, int Jp_x, int Jp_dy, float* work, long long work_floats,
+                                  float* dw_re, float* dw_im, void* stream);
 /* bias gradients (b_re enters real as +, imag as +; b_im real as -, imag as +; complex_progress.py:16-18) from
  * idv_cbn_stats(dy): db_re = sum dy_r + sum dy_i, db_im = sum dy_i - sum dy_r. */
 int idv_cconv2d_bwd_bias(const double* stats_dy, int Cout, float* db_re, float* db_im, void* stream);
