@@ -269,6 +269,115 @@ __global__ void cconv_bias_grad_kernel(const double* __restrict__ stats, int Cou
     db_im[c] = (float)(si - sr);
 }
 
+
+// ---- one-channel ends of the network (first encoder block: Cin = 1, last decoder block: Cout = 1): L has 2 planes --------
+// Against the 128 x 32 plane MFMA tile such a layer fills 2 of 32 columns (3 TFLOP/s, 10 ms of the train step for 0.2 % of
+// its flops).  The work is tiny and memory-shaped (one pass over S = 64 .. 128 planes), so it runs on the vector ALU: a lane
+// owns a column j, a workgroup SK_SP planes of S x a column range x all frequency rows; per (fs, j) it reads the 5 x 2 x 2
+// window of L once (sliding over fs: 3 of the 5 rows carry over) and does SK_SP x 20 FMAs into register accumulators,
+// reduced over lanes (DPP), waves (LDS) and column splits (the same partial-tile workspace + unpack kernel as the MFMA path).
+constexpr int SK_SP = 4, SK_LP = 2, SK_TAPS = 10;
+
+__global__ __launch_bounds__(256) void wgrad_skinny_kernel(const WgradArgs a, int cols_per_split) {
+    __shared__ float red[4][SK_SP * SK_LP * SK_TAPS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x, sp0 = blockIdx.y * SK_SP;
+    const int jbeg = split * cols_per_split;
+    int jend = jbeg + cols_per_split;
+    if (jend > a.J) jend = a.J;
+    float acc[SK_SP][SK_LP][SK_TAPS];
+#pragma unroll
+    for (int s = 0; s < SK_SP; ++s)
+#pragma unroll
+        for (int l = 0; l < SK_LP; ++l)
+#pragma unroll
+            for (int t = 0; t < SK_TAPS; ++t) acc[s][l][t] = 0.f;
+    for (int j = jbeg + tid; j < jend; j += 256) {
+        const int jl = j + a.dt0;                    // L columns jl (kt = 0) and jl + 1 (kt = 1)
+        const bool ok0 = jl >= 0 && jl < a.J, ok1 = jl + 1 >= 0 && jl + 1 < a.J;
+        // window rows fl = 2 fs + kf - 2; w[l][kf][kt]
+        float w[SK_LP][5][2];
+        auto load_row = [&](int l, int fl, float (&o)[2]) {
+            const bool rok = (l < a.Lp) && fl >= 0 && fl < a.Fl;
+            const float* r = a.L + ((size_t)(rok ? l : 0) * a.Fl + (rok ? fl : 0)) * a.JpL;
+            o[0] = (rok && ok0) ? r[jl] : 0.f;
+            o[1] = (rok && ok1) ? r[jl + 1] : 0.f;
+        };
+#pragma unroll
+        for (int l = 0; l < SK_LP; ++l)
+#pragma unroll
+            for (int kf = 0; kf < 5; ++kf) load_row(l, kf - 2, w[l][kf]);
+        for (int fs = 0; fs < a.Fs; ++fs) {
+            float sv[SK_SP];
+#pragma unroll
+            for (int s = 0; s < SK_SP; ++s) {
+                const int sp = sp0 + s;
+                sv[s] = sp < a.Sp ? a.S[((size_t)sp * a.Fs + fs) * a.JpS + j] : 0.f;
+            }
+            // next window's two new rows in flight under this row's FMAs
+            float nw[SK_LP][2][2];
+#pragma unroll
+            for (int l = 0; l < SK_LP; ++l) {
+                load_row(l, 2 * (fs + 1) + 1, nw[l][0]);
+                load_row(l, 2 * (fs + 1) + 2, nw[l][1]);
+            }
+#pragma unroll
+            for (int s = 0; s < SK_SP; ++s)
+#pragma unroll
+                for (int l = 0; l < SK_LP; ++l)
+#pragma unroll
+                    for (int kf = 0; kf < 5; ++kf) {
+                        acc[s][l][kf * 2] += sv[s] * w[l][kf][0];
+                        acc[s][l][kf * 2 + 1] += sv[s] * w[l][kf][1];
+                    }
+#pragma unroll
+            for (int l = 0; l < SK_LP; ++l) {
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf) {
+                    w[l][kf][0] = w[l][kf + 2][0];
+                    w[l][kf][1] = w[l][kf + 2][1];
+                }
+                w[l][3][0] = nw[l][0][0]; w[l][3][1] = nw[l][0][1];
+                w[l][4][0] = nw[l][1][0]; w[l][4][1] = nw[l][1][1];
+            }
+        }
+    }
+    // lanes -> waves -> workgroup
+#pragma unroll
+    for (int s = 0; s < SK_SP; ++s)
+#pragma unroll
+        for (int l = 0; l < SK_LP; ++l)
+#pragma unroll
+            for (int t = 0; t < SK_TAPS; ++t) {
+                float v = acc[s][l][t];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                if (lane == 0) red[wave][(s * SK_LP + l) * SK_TAPS + t] = v;
+            }
+    __syncthreads();
+    if (tid < SK_SP * SK_LP * SK_TAPS) {
+        const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        const int t = tid % SK_TAPS, l = (tid / SK_TAPS) % SK_LP, s = tid / (SK_TAPS * SK_LP);
+        a.part[(((size_t)split * SK_TAPS + t) * a.SpPad + sp0 + s) * a.LpPad + l] = v;
+    }
+}
+
+struct SkinnyPlan { int groups, nsplit, cols_per_split, SpPad, LpPad; };
+
+inline SkinnyPlan skinny_plan(int Sp, int J) {
+    SkinnyPlan p;
+    p.groups = (Sp + SK_SP - 1) / SK_SP;
+    p.SpPad = p.groups * SK_SP;
+    p.LpPad = SK_LP;
+    int want = (2048 + p.groups - 1) / p.groups;
+    const int maxsplit = (J + 255) / 256;
+    if (want > maxsplit) want = maxsplit;
+    if (want < 1) want = 1;
+    p.cols_per_split = ((J + want - 1) / want + 255) / 256 * 256;
+    p.nsplit = (J + p.cols_per_split - 1) / p.cols_per_split;
+    return p;
+}
+
 constexpr int CONV_JT = 16, PW_JT = 32;
 constexpr int CONV_MS = 128, CONV_ML = 32;      // wgrad_kernel<5, 2, 1, 1, 4, 1, ...>: 4 x 1 waves of one 32 x 32 tile x 10 taps
 
@@ -283,6 +392,10 @@ void launch_wgrad_unpack_conv(const float* part, int nsplit, int SpPad, int LpPa
 
 extern "C" long long idv_cconv_wgrad_work_floats(int Cs, int Cl, int B, int Tp) {
     if (Cs <= 0 || Cl <= 0 || B <= 0 || Tp <= 0) return -1;
+    if (2 * Cl <= SK_LP) {
+        const SkinnyPlan k = skinny_plan(2 * Cs, B * Tp);
+        return (long long)k.nsplit * 10 * k.SpPad * k.LpPad;
+    }
     const Plan p = make_plan(2 * Cs, 2 * Cl, B * Tp, CONV_MS, CONV_ML, CONV_JT);
     return (long long)p.nsplit * 10 * p.SpPad * p.LpPad;
 }
@@ -309,10 +422,19 @@ extern "C" int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const 
         a.dt0 = 0;
     }
     a.J = B * Tp;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.Lp <= SK_LP) {      // one-channel end of the network: vector-ALU kernel (see wgrad_skinny_kernel)
+        const SkinnyPlan k = skinny_plan(a.Sp, a.J);
+        if ((long long)k.nsplit * 10 * k.SpPad * k.LpPad > work_floats) return IDV_EINVAL;
+        a.part = work; a.SpPad = k.SpPad; a.LpPad = k.LpPad;
+        hipLaunchKernelGGL(wgrad_skinny_kernel, dim3(k.nsplit, k.groups), dim3(256), 0, st, a, k.cols_per_split);
+        hipLaunchKernelGGL(wgrad_unpack_conv_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work, k.nsplit,
+                           k.SpPad, k.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
+        return idv_launch_status();
+    }
     const Plan p = make_plan(a.Sp, a.Lp, a.J, CONV_MS, CONV_ML, CONV_JT);
     if ((long long)p.nsplit * 10 * p.SpPad * p.LpPad > work_floats) return IDV_EINVAL;
     a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles; a.jt_per_split = p.jt_per_split;
-    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 4, 1, CONV_JT, 2>), dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_unpack_conv_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work, p.nsplit,
                        p.SpPad, p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
