@@ -26,22 +26,28 @@ constexpr int BW_MS = 128, BW_ML = 32, BW_JT = 32, BW_KF = 5;
 constexpr int BW_PITCH = BW_JT + 8;                 // bf16 elements per LDS row: 80 bytes = 5 x 16 (odd): conflict-free b128 reads
 constexpr int BW_LROWS = BW_ML * BW_KF;             // 160
 
-__device__ __forceinline__ void split4(const f32x4 v, const bool (&ok)[4], uint2& hi, uint2& lo) {
-    unsigned h[4];
-    float r[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float x = ok[c] ? v[c] : 0.f;
-        h[c] = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
-        r[c] = x - __builtin_bit_cast(float, h[c]);
-    }
-    hi = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-    lo = make_uint2(pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3]));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned hi_bits(float x) { return __builtin_bit_cast(unsigned, x) & 0xffff0000u; }
+
+// (hi, lo) bf16 quadruples of four floats: hi = the value truncated to bf16, lo = bf16(x - hi)
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo) {
+    const unsigned h0 = hi_bits(x0), h1 = hi_bits(x1), h2 = hi_bits(x2), h3 = hi_bits(x3);
+    hi = make_uint2((h0 >> 16) | h1, (h2 >> 16) | h3);
+    lo = make_uint2(pack_bf16(x0 - __builtin_bit_cast(float, h0), x1 - __builtin_bit_cast(float, h1)),
+                    pack_bf16(x2 - __builtin_bit_cast(float, h2), x3 - __builtin_bit_cast(float, h3)));
 }
 
+// D = +1 (dt0 == 0) or -1 (dt0 == -1): direction of the shifted copy of the L tile.
+// Staging goes through raw buffer loads: an invalid slot (plane or frequency row outside the tensor, column >= J) gets the
+// byte offset 0x80000000 (beyond the tensor), which the hardware answers with zeros -- no per-element masks (they were 2/3 of the 620 vector
+// instructions per step that bounded the first version at 190 TFLOP/s).  Needs J % 4 == 0 (a float4 never straddles J) and
+// tensors below 2 GB (host-checked).
+template <int D>
 __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
     constexpr int Q4 = BW_JT / 4;                                       // float4 slots per row
     constexpr int NS4 = BW_MS * Q4 / 256, NL4 = BW_LROWS * Q4 / 256;    // 4, 5
+    constexpr unsigned OOB = 0x80000000u;       // beyond num_records (< 2 GB) and far from the 32-bit wrap of offset + size
     __shared__ __attribute__((aligned(16))) unsigned short Ssm[2][BW_MS][BW_PITCH];          // [hi|lo]
     __shared__ __attribute__((aligned(16))) unsigned short Lsm[2][2][BW_LROWS][BW_PITCH];    // [aligned|shifted][hi|lo]
 
@@ -55,10 +61,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
     int jt1 = jt0 + a.jt_per_split;
     if (jt1 > a.jtiles) jt1 = a.jtiles;
     const int nsteps = (jt1 > jt0) ? (jt1 - jt0) * a.Fs : 0;
-    // L column = S column + kt + dt0: the aligned copy serves kt + dt0 == 0, the copy shifted by d = (dt0 == 0 ? +1 : -1)
-    // the other tap
-    const int d = a.dt0 == 0 ? 1 : -1;
+    // L column = S column + kt + dt0: the aligned copy serves kt + dt0 == 0, the copy shifted by D the other tap
     const int my_copy = (wt + a.dt0 == 0) ? 0 : 1;
+    const __amdgpu_buffer_rsrc_t Sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.S, 0, (unsigned)((size_t)a.Sp * a.Fs * a.JpS * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t Lr = __builtin_amdgcn_make_buffer_rsrc((void*)a.L, 0, (unsigned)((size_t)a.Lp * a.Fl * a.JpL * 4), 0x00020000);
 
     f32x16 acc[2][BW_KF];
 #pragma unroll
@@ -68,81 +74,81 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
+    // per-thread constants of the staging slots: q is the same for every slot of a thread (256 % 8 == 0)
+    const int q = tid & (Q4 - 1);
+    unsigned sbase[NS4], lbase[NL4];         // byte offset of (plane, row 0 [+ kf], column 4q); OOB when the plane is padding
+    int lkf[NL4];
+#pragma unroll
+    for (int i = 0; i < NS4; ++i) {
+        const int row = (tid + i * 256) / Q4;
+        const int sp = sp0 + row;
+        sbase[i] = sp < a.Sp ? (unsigned)(((size_t)sp * a.Fs * a.JpS + 4 * q) * 4) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < NL4; ++i) {
+        const int row = (tid + i * 256) / Q4;
+        const int pl = row / BW_KF, kf = row - pl * BW_KF;
+        const int lp = lp0 + pl;
+        lkf[i] = kf;
+        lbase[i] = lp < a.Lp ? (unsigned)((((size_t)lp * a.Fl + kf) * a.JpL + 4 * q) * 4) : OOB;
+    }
+    const bool edge_lane = D > 0 ? (q == Q4 - 1) : (q == 0);
+
     f32x4 sreg[NS4], lreg[NL4];
     float hreg[NL4];
 
-    // Branch-free staging (see wgrad.hip): every slot loads unconditionally, invalid slots read element 0; the masks are
-    // applied when the registers are split and written to LDS one step later.
     auto load_step = [&](int step) {
         const int jt = jt0 + step / a.Fs, fs = step - (step / a.Fs) * a.Fs;
         const int j0 = jt * BW_JT;
+        const bool colok = j0 + 4 * q < a.J;
+        const unsigned us = (unsigned)(((long long)fs * a.JpS + j0) * 4);
 #pragma unroll
         for (int i = 0; i < NS4; ++i) {
-            const int e = tid + i * 256;
-            const int row = e / Q4, q = e - row * Q4;
-            const int sp = sp0 + row, j = j0 + 4 * q;
-            const bool ok = (sp < a.Sp) && (j < a.J);
-            const size_t off = ok ? ((size_t)sp * a.Fs + fs) * a.JpS + j : 0;
-            sreg[i] = *(const f32x4*)(a.S + off);
+            const unsigned off = (colok && sbase[i] != OOB) ? sbase[i] + us : OOB;
+            sreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(Sr, off, 0, 0));
         }
+        const unsigned ul = (unsigned)(((long long)(2 * fs - 2) * a.JpL + j0) * 4);     // wraps for fs = 0: only used when valid
+        const int je = D > 0 ? j0 + BW_JT : j0 - 1;                                     // edge column of the shifted copy
+        const bool eok = edge_lane && je >= 0 && je < a.J;
+        const unsigned ue = (unsigned)(((long long)(2 * fs - 2) * a.JpL + je - 4 * q) * 4);
 #pragma unroll
         for (int i = 0; i < NL4; ++i) {
-            const int e = tid + i * 256;
-            const int row = e / Q4, q = e - row * Q4;
-            const int pl = row / BW_KF, kf = row - pl * BW_KF;
-            const int lp = lp0 + pl, fl = 2 * fs + kf - 2, j = j0 + 4 * q;
-            const bool rok = (lp < a.Lp) && (fl >= 0) && (fl < a.Fl);
-            const size_t base = rok ? ((size_t)lp * a.Fl + fl) * a.JpL : 0;
-            lreg[i] = *(const f32x4*)(a.L + base + ((rok && j < a.J) ? j : 0));
-            // edge element of the shifted copy: column j0 + 32 (d = +1, slot q = 7) or j0 - 1 (d = -1, slot q = 0)
-            const int je = d > 0 ? j0 + BW_JT : j0 - 1;
-            hreg[i] = a.L[base + ((rok && je >= 0 && je < a.J) ? je : 0)];
+            const int fl = 2 * fs + lkf[i] - 2;
+            const bool rok = lbase[i] != OOB && fl >= 0 && fl < a.Fl;
+            lreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(Lr, (rok && colok) ? lbase[i] + ul : OOB, 0, 0));
+            hreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Lr, (rok && eok) ? lbase[i] + ue : OOB, 0, 0));
         }
     };
-    auto store_step = [&](int step) {
-        const int jt = jt0 + step / a.Fs, fs = step - (step / a.Fs) * a.Fs;
-        const int j0 = jt * BW_JT;
+    auto store_step = [&]() {
 #pragma unroll
         for (int i = 0; i < NS4; ++i) {
-            const int e = tid + i * 256;
-            const int row = e / Q4, q = e - row * Q4;
-            const int sp = sp0 + row, j = j0 + 4 * q;
-            bool ok[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ok[c] = (sp < a.Sp) && (j + c < a.J);
+            const int row = (tid + i * 256) / Q4;
             uint2 hi, lo;
-            split4(sreg[i], ok, hi, lo);
+            split4(sreg[i][0], sreg[i][1], sreg[i][2], sreg[i][3], hi, lo);
             *(uint2*)&Ssm[0][row][4 * q] = hi;
             *(uint2*)&Ssm[1][row][4 * q] = lo;
         }
 #pragma unroll
         for (int i = 0; i < NL4; ++i) {
-            const int e = tid + i * 256;
-            const int row = e / Q4, q = e - row * Q4;
-            const int pl = row / BW_KF, kf = row - pl * BW_KF;
-            const int lp = lp0 + pl, fl = 2 * fs + kf - 2, j = j0 + 4 * q;
-            const bool rok = (lp < a.Lp) && (fl >= 0) && (fl < a.Fl);
-            // aligned copy: columns j .. j+3
-            f32x4 v = lreg[i];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = (rok && j + c < a.J) ? v[c] : 0.f;
-            // shifted copy: columns j+d .. j+d+3 = own elements + the neighbour slot's edge element (lanes e +- 1 hold the
-            // neighbouring float4 of the same row; at the row ends the separately loaded edge element)
-            const int je = d > 0 ? j0 + BW_JT : j0 - 1;
-            const float edge = (rok && je >= 0 && je < a.J) ? hreg[i] : 0.f;
-            const float nb = d > 0 ? __shfl_down(v[0], 1) : __shfl_up(v[3], 1);
+            const int row = (tid + i * 256) / Q4;
+            const f32x4 v = lreg[i];
+            // shifted copy: columns j+D .. j+D+3 = own elements + the neighbour slot's edge element (lanes +-1 hold the
+            // neighbouring float4 of the same row: DPP row shift; at the row ends the separately loaded edge element)
+            // (float temporaries: __builtin_bit_cast applied directly to a vector element reads element 0 on this compiler)
+            const float v_first = v[0], v_last = v[3];
             f32x4 w;
-            if (d > 0) {
-                w[0] = v[1]; w[1] = v[2]; w[2] = v[3]; w[3] = (q == Q4 - 1) ? edge : nb;
+            if (D > 0) {
+                const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v_first), 0x101, 0xf, 0xf, true));
+                w[0] = v[1]; w[1] = v[2]; w[2] = v[3]; w[3] = edge_lane ? hreg[i] : nb;      // row_shl:1 = lane + 1
             } else {
-                w[0] = (q == 0) ? edge : nb; w[1] = v[0]; w[2] = v[1]; w[3] = v[2];
+                const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v_last), 0x111, 0xf, 0xf, true));
+                w[0] = edge_lane ? hreg[i] : nb; w[1] = v[0]; w[2] = v[1]; w[3] = v[2];      // row_shr:1 = lane - 1
             }
-            const bool all[4] = {true, true, true, true};
             uint2 hi, lo;
-            split4(v, all, hi, lo);
+            split4(v[0], v[1], v[2], v[3], hi, lo);
             *(uint2*)&Lsm[0][0][row][4 * q] = hi;
             *(uint2*)&Lsm[0][1][row][4 * q] = lo;
-            split4(w, all, hi, lo);
+            split4(w[0], w[1], w[2], w[3], hi, lo);
             *(uint2*)&Lsm[1][0][row][4 * q] = hi;
             *(uint2*)&Lsm[1][1][row][4 * q] = lo;
         }
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
 
     if (nsteps > 0) load_step(0);
     for (int step = 0; step < nsteps; ++step) {
-        store_step(step);
+        store_step();
         __syncthreads();
         if (step + 1 < nsteps) load_step(step + 1);      // global loads fly under this step's MFMAs
         const unsigned short* Ah = &Ssm[0][wm * 64 + l31][half * 8];
@@ -210,7 +216,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
 extern "C" long long idv_cconv_wgrad_bf16_work_floats(int Cs, int Cl, int B, int Tp) {
     if (Cs <= 0 || Cl <= 0 || B <= 0 || Tp <= 0) return -1;
     const Plan p = make_plan(2 * Cs, 2 * Cl, B * Tp, BW_MS, BW_ML, BW_JT);
-    return (long long)p.nsplit * 10 * p.SpPad * p.LpPad;
+    const long long n = (long long)p.nsplit * 10 * p.SpPad * p.LpPad, nf = idv_cconv_wgrad_work_floats(Cs, Cl, B, Tp);
+    return n > nf ? n : nf;          // covers the exact-fp32 fallback as well
 }
 
 // idv_cconv2d_bwd_weight in split-bf16 arithmetic (bf16x3 training mode); arguments as there, work:
@@ -237,11 +244,20 @@ extern "C" int idv_cconv2d_bwd_weight_bf16x3(const float* x, int Cx, int ci_off,
         a.dt0 = 0;
     }
     a.J = B * Tp;
+    // the buffer-load staging needs whole float4s inside J and 32-bit byte offsets; anything else: the exact-fp32 kernel
+    if ((a.J % 4) || (size_t)a.Sp * a.Fs * a.JpS * 4 >= 0x7ffffff0ull || (size_t)a.Lp * a.Fl * a.JpL * 4 >= 0x7ffffff0ull) {
+        if (idv_cconv_wgrad_work_floats(transposed ? Cx : Cout, transposed ? Cout : Cx, B, Tp) > work_floats) return IDV_EINVAL;
+        return idv_cconv2d_bwd_weight(x, Cx, ci_off, dy, Cout, Cin_total, transposed, tshift, Fin, B, Tp, Jp_x, Jp_dy, work,
+                                      work_floats, dw_re, dw_im, stream);
+    }
     const Plan p = make_plan(a.Sp, a.Lp, a.J, BW_MS, BW_ML, BW_JT);
     if ((long long)p.nsplit * 10 * p.SpPad * p.LpPad > work_floats) return IDV_EINVAL;
     a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles; a.jt_per_split = p.jt_per_split;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
+    if (a.dt0 == 0)
+        hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(wgrad_bf16_kernel<-1>, dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
     launch_wgrad_unpack_conv(work, p.nsplit, p.SpPad, p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im, st);
     return idv_launch_status();
 }
