@@ -584,11 +584,11 @@ __global__ void zero_tail_kernel(float* __restrict__ act, int planes, int B, int
 
 int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
     dim3 grid((ra.B + 15) / 16, 4);
-    if ((flags & 1) && !(flags & 8) && cstate && !ra.gsave && idv_lstm_pers_supported(ra.H, ra.B)) {
+    if ((flags & 1) && !(flags & 8) && cstate && idv_lstm_pers_supported(ra.H, ra.B)) {
         // H = 384 / 768 (VAE encoders), split-bf16 mode: one persistent cooperative launch per layer (lstm_pers.hip);
         // its exchange buffer lives in the scratch behind cstate (idv_clstm_work_floats covers it: 4*H*Jp floats)
         return idv_lstm_rec_pers(ra.g, ra.g_run_z, ra.g_run_s, ra.ldg, ra.whh, ra.kimg ? nullptr : ra.hout, ra.H, ra.B, ra.T,
-                                 (void*)(cstate + 4LL * ra.B * ra.H), ra.kimg, ra.kimg_lo, ra.Tp, ra.Jp, (void*)st);
+                                 (void*)(cstate + 4LL * ra.B * ra.H), ra.kimg, ra.kimg_lo, ra.Tp, ra.Jp, ra.gsave, ra.csave, (void*)st);
     }
     if (ra.H == 128 && (flags & 1)) {
         hipLaunchKernelGGL(lstm_rec_bf16_kernel, grid, dim3(256), 0, st, ra);
@@ -637,7 +637,9 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     hipStream_t st = (hipStream_t)stream;
     const long long TB = (long long)T * B;
     const bool save = (flags & 4) != 0;
-    if (save && (flags & 1)) return IDV_EINVAL;         // the training forward keeps the exact-fp32 recurrence
+    // training forward in split-bf16 mode: only where the persistent recurrence exists (H = 384 / 768); H = 128 and the
+    // generic sizes keep the exact-fp32 recurrence
+    if (save && (flags & 1) && ((flags & 8) || !idv_lstm_pers_supported(H, B))) return IDV_EINVAL;
     float* G = work;                       // [2][TB][8H]  then (inference: same memory)  [4][TB][4H]
     float* G1 = save ? work + 16 * TB * H : work;
     float* h0 = (save ? G1 : work) + 16 * TB * H;        // [4][TB][H]

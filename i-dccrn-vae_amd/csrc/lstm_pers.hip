@@ -31,6 +31,8 @@ struct PersArgs {
     int ldg;
     const uint4* whh16;       // split-bf16 fragments of idv_pack_lstm_hh: [set][tile = ub*4 + gate][kb][hi|lo][lane]
     float* hout;              // [4 runs][T*B][H]  (nullptr: not wanted)
+    float* gsave;             // training: activated gates (i, f, g, o) written back over the pre-activations (= g), or nullptr
+    float* csave;             // training: cell state per step [4 runs][T*B][H], or nullptr
     uint4* kimg;              // or nullptr: K-major split image of h_t, slot ((run * H/8 + octet) * Jp + b * Tp + t + 1)
     long long kimg_lo;        //   hi -> lo distance in 16-byte slots
     int Tp, Jp;
@@ -228,6 +230,15 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
             const float cn = fg * creg[rt] + ig * gv;
             creg[rt] = cn;
             const float hv = og * tanhf_(cn);
+            if (a.gsave) {                           // what idv_lstm_bptt reads: the same layout the per-step kernels leave
+                const int z = t_run[rt] >> 1;
+                int b = t_b0[rt] + myrow;
+                if (t_ok[rt] && b < a.B) {
+                    float* gp = a.gsave + z * a.g_run_z + s * a.g_run_s + ((size_t)t * a.B + b) * a.ldg + sl * 64 + col;
+                    gp[0] = ig; gp[16] = fg; gp[32] = gv; gp[48] = og;
+                    a.csave[(size_t)t_run[rt] * TBH + ((size_t)t * a.B + b) * H + sl * 16 + col] = cn;
+                }
+            }
             const __bf16 hh = (__bf16)hv;
             const __bf16 hl = (__bf16)(hv - (float)hh);
             // transpose through LDS: a lane holds one unit of one row, a 16-byte store wants 8 units of a row
@@ -320,14 +331,16 @@ static unsigned long long* g_prof = nullptr;
 extern "C" void idv_lstm_pers_set_profile(unsigned long long* prof_cycles) { g_prof = prof_cycles; }
 
 // one layer of the recurrence; work: idv_lstm_pers_work_bytes(H, B) bytes (16-byte aligned), contents arbitrary.
-// Outputs, at least one: hout [4 runs][T*B][H] fp32 and / or kimg, the K-major split image of h (4 runs x H/8 octets x Jp
+// gsave (== g) / csave: training forward, the activated gates overwrite the pre-activations and the cell states are kept
+// for idv_lstm_bptt (layouts as idv_clstm_fwd flags bit 2).  Outputs, at least one: hout [4 runs][T*B][H] fp32 and / or kimg, the K-major split image of h (4 runs x H/8 octets x Jp
 // columns, column b*Tp + t + 1; kimg_lo_slots 16-byte slots from the hi to the lo plane) that idv_lstm_proj1_bf16x3 reads.
 extern "C" int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh_frag, float* hout,
                                  int H, int B, int T, void* work, void* kimg, long long kimg_lo_slots, int Tp, int Jp,
-                                 void* stream) {
+                                 float* gsave, float* csave, void* stream) {
     using namespace idv_pers;
     unsigned long long* prof = g_prof;
     if (!g || !whh_frag || (!hout && !kimg) || !work || T <= 0 || !idv_lstm_pers_supported(H, B)) return IDV_EINVAL;
+    if ((gsave != nullptr) != (csave != nullptr) || (gsave && gsave != g)) return IDV_EINVAL;   // gates are saved in place
     if (reinterpret_cast<uintptr_t>(work) & 15) return IDV_EINVAL;
     if (kimg && ((reinterpret_cast<uintptr_t>(kimg) & 15) || Tp < T + 1 || Jp < B * Tp || kimg_lo_slots < 4LL * (H / 8) * Jp))
         return IDV_EINVAL;
@@ -350,6 +363,7 @@ extern "C" int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_
     a.whh16 = (const uint4*)(whh_frag + (size_t)2 * 4 * H * H);
     a.hout = hout;
     a.kimg = (uint4*)kimg; a.kimg_lo = kimg_lo_slots; a.Tp = Tp; a.Jp = Jp;
+    a.gsave = gsave; a.csave = csave;
     a.sync = (unsigned*)work;
     a.hx = (unsigned short*)((char*)work + SYNC_BYTES);
     a.hx_bytes = (unsigned)hx_bytes;

@@ -199,7 +199,8 @@ long long idv_clstm_work_floats(int H, int B, int T, int Jp);   /* 24*T*B*H + 4*
 int idv_lstm_pers_supported(int H, int B);
 long long idv_lstm_pers_work_bytes(int H, int B);
 int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh_frag, float* hout, int H,
-                      int B, int T, void* work, void* kimg, long long kimg_lo_slots, int Tp, int Jp, void* stream);
+                      int B, int T, void* work, void* kimg, long long kimg_lo_slots, int Tp, int Jp, float* gsave, float* csave,
+                      void* stream);   /* gsave (== g) / csave: training forward, layouts of idv_clstm_fwd flags bit 2; or NULL */
 /* Layer-1 input projection (nn.LSTM weight_ih_l1 of lstm_re / lstm_im, complex_progress.py:50-74) in split-bf16 from that
  * image: G1[run = 2z + s][(t, b)][4H].  wfrag_bf16: idv_pack_lstm_ih_bf16(w_ih_l1 re, im, H, K = H); bias: bih1 of
  * idv_pack_lstm_ih.  Needs 4H % 256 == 0 and H % 64 == 0. */
@@ -209,7 +210,7 @@ int idv_lstm_proj1_bf16x3(const void* himg, long long lo_off_slots, const void* 
  * an instrumented twin in which every workgroup accumulates core-clock cycles per phase (spin, -, barrier, loads + MFMA,
  * reduce + cell, drain + barrier, -, XCC id); NULL restores the production kernel.  tests/tools/lstm_phase_probe.py */
 void idv_lstm_pers_set_profile(unsigned long long* prof_cycles);
-/* flags bit 2 (training forward, exact-fp32 recurrence only): the activated gates (i, f, g, o) and the cell states are kept
+/* flags bit 2 (training forward; with bit 0 only where idv_lstm_pers_supported, else EINVAL: exact-fp32 recurrence): the activated gates (i, f, g, o) and the cell states are kept
  * for idv_lstm_bptt.  work then holds idv_clstm_train_work_floats floats, laid out (TBH = T*B*H)
  *   [G0 16 TBH | G1 16 TBH | h0 4 TBH | h1 4 TBH | c0 4 TBH | c1 4 TBH | scratch]
  * G0: [z][T*B][8H] (z = real / imag input; columns [weight set s][4H]), G1: [run = 2z+s][T*B][4H], h/c: [run][T*B][H];

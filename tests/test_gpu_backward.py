@@ -164,6 +164,22 @@ def _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, ftol,
 @pytest.mark.parametrize("H,I,T,B", [(16, 20, 7, 3), (128, 64, 12, 5), (128, 160, 30, 18), (48, 32, 6, 2), (96, 160, 9, 17),
                                      (384, 64, 5, 3)])
 def test_clstm_grads(ops, cp, H, I, T, B):
+    _clstm_grads(ops, cp, H, I, T, B, 2e-5, GTOL)
+
+
+@pytest.mark.parametrize("H,I,T,B", [(384, 64, 9, 3), (768, 128, 7, 20), (384, 1280, 33, 32)])
+def test_clstm_grads_bf16x3(ops, cp, H, I, T, B):
+    """bf16x3 training mode at the VAE encoders' hidden sizes: the forward recurrence is the persistent split-bf16 kernel,
+    which also leaves the activated gates and cell states for the fp32 BPTT kernels (1, 2 and 4 row tiles per workgroup)."""
+    keep = ops.PRECISION
+    ops.set_precision("bf16x3")
+    try:
+        _clstm_grads(ops, cp, H, I, T, B, 1e-4, 1e-3)
+    finally:
+        ops.set_precision(keep)
+
+
+def _clstm_grads(ops, cp, H, I, T, B, ftol, gtol):
     g = torch.Generator().manual_seed(11)
     dev = "cuda"
     m = cp.ComplexLSTM(I, H, dev, num_layers=2)
@@ -182,12 +198,12 @@ def test_clstm_grads(ops, cp, H, I, T, B):
     sd = {k: leaf64(v.cpu()) for k, v in m.state_dict().items()}
     x64 = leaf64(x)
     want = O.complex_lstm(x64, sd, "", 2)
-    check("forward", y, want, 2e-5)
+    check("forward", y, want, ftol)
     (want * R.double()).sum().backward()
     gx = ops.rewrap(xp.buf.grad, xp).tensor5()                          # [B, I, 1, T, 2]
-    check("dx", gx[:, :, 0].permute(2, 0, 1, 3), x64.grad)
+    check("dx", gx[:, :, 0].permute(2, 0, 1, 3), x64.grad, gtol)
     for k, p_ in m.named_parameters():
-        check(k, p_.grad, sd[k].grad)
+        check(k, p_.grad, sd[k].grad, gtol)
 
 
 # ----------------------------------------------------------------------------- dense, mask, STFT / ISTFT
