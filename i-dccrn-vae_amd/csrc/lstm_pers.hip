@@ -17,6 +17,7 @@
 // Every spin is bounded: a workgroup that waits longer than ~0.4 s raises the abort flag, all workgroups drain, and the
 // outputs are poisoned with NaN (no hang; results never silently wrong).
 #include <cstdlib>
+#include <mutex>
 #include "common.hpp"
 #include "../../include/idccrn_hip.h"
 
@@ -321,6 +322,13 @@ extern "C" long long idv_lstm_pers_work_bytes(int H, int B) {
     return SYNC_BYTES + 2LL * 4 * Bpad * H * 4;       // [abort flag + arrive counters, zeroed per call][exchange]
 }
 
+// Two cooperative launches must never share the chip: each needs ALL its workgroups resident (it spins on its siblings), and
+// two half-resident launches on different streams would wait for each other until the spin bound poisons both.  Launches
+// from different streams of one device are therefore chained through an event (other kernels may still overlap them).
+static std::mutex g_pers_mu;
+static hipEvent_t g_pers_done[16] = {};
+static hipStream_t g_pers_stream[16] = {};
+
 static unsigned long long* g_prof = nullptr;
 
 // diagnostic: while a device buffer of 256 x 8 counters is registered, idv_lstm_rec_pers launches the instrumented twin of
@@ -382,11 +390,18 @@ extern "C" int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_
             return IDV_ELAUNCH;                                                                                           \
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, a);                                                              \
     } while (0)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return IDV_ELAUNCH;
+    std::lock_guard<std::mutex> lock(g_pers_mu);
+    if (g_pers_done[dev] && g_pers_stream[dev] != st && hipStreamWaitEvent(st, g_pers_done[dev], 0) != hipSuccess) return IDV_ELAUNCH;
     if (H == 384) {
         if (nrt == 1) IDV_PERS_LAUNCH(3, 1); else if (nrt == 2) IDV_PERS_LAUNCH(3, 2); else IDV_PERS_LAUNCH(3, 4);
     } else {
         if (nrt == 1) IDV_PERS_LAUNCH(6, 1); else if (nrt == 2) IDV_PERS_LAUNCH(6, 2); else IDV_PERS_LAUNCH(6, 4);
     }
 #undef IDV_PERS_LAUNCH
+    if (!g_pers_done[dev] && hipEventCreateWithFlags(&g_pers_done[dev], hipEventDisableTiming) != hipSuccess) return IDV_ELAUNCH;
+    if (hipEventRecord(g_pers_done[dev], st) != hipSuccess) return IDV_ELAUNCH;
+    g_pers_stream[dev] = st;
     return idv_launch_status();
 }

@@ -3,7 +3,8 @@
 #   1. rocprofv3 --kernel-trace --stats of the DEFAULT bench command (fp32 headline + bf16x3 alt record)
 #   2. --stats of the fp32 headline alone and of the bf16x3 mode alone (one stream each)
 #   3. --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, for both modes  -> r02_traffic_f32.json / r02_traffic_bf16x3.json
-#   4. --stats of the DCCRN-CL train step (forward + loss + backward + Adam, B = 32)
+#   4. --stats of the DCCRN-CL train step (forward + loss + backward + Adam, B = 32), fp32 and bf16x3 training mode
+#   5. --stats of the VAE workloads (NSVAE encoders + KL, two-phase decoder forward, NSVAE train step), B = 32, bf16x3
 # Counter passes carry only --kernel-trace (no sys/hip/hsa trace domains).  Outputs land in gpurun_out/prof_<tag>/.
 set -o pipefail
 tag=${1:-r02}
@@ -20,6 +21,10 @@ run bench_default $S -d "$out/stats_default" -- python3 bench.py --steps 5 --war
 run bench_f32 $S -d "$out/stats_f32" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt
 run bench_bf16x3 $S -d "$out/stats_bf16x3" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --precision bf16x3
 run bench_train $S -d "$out/stats_train" -- python3 bench.py --workload dccrn_cl_train --steps 3 --warmup 1 --no-cpu-baseline
+run bench_train_bf16x3 $S -d "$out/stats_train_bf16x3" -- python3 bench.py --workload dccrn_cl_train --precision bf16x3 --steps 3 --warmup 1 --no-cpu-baseline
+run bench_nsvae_kl $S -d "$out/stats_nsvae_kl" -- python3 bench.py --workload nsvae_kl --precision bf16x3 --batch 32 --steps 4 --warmup 2 --no-cpu-baseline
+run bench_twophase $S -d "$out/stats_twophase" -- python3 bench.py --workload twophase --precision bf16x3 --batch 32 --steps 4 --warmup 2 --no-cpu-baseline
+run bench_nsvae_train_bf16x3 $S -d "$out/stats_nsvae_train_bf16x3" -- python3 bench.py --workload nsvae_train --precision bf16x3 --steps 3 --warmup 1 --no-cpu-baseline
 P="--kernel-trace --output-format csv"
 for mode in f32 bf16x3; do
   prec=$([ $mode = f32 ] && echo fp32 || echo bf16x3)

@@ -11,7 +11,7 @@ import sys
 src = sys.argv[1]
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
-for name in ("default", "f32", "bf16x3", "train"):
+for name in ("default", "f32", "bf16x3", "train", "train_bf16x3", "nsvae_kl", "twophase", "nsvae_train_bf16x3"):
     for f in glob.glob(os.path.join(src, "stats_" + name, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, f"kernel_stats_{name}.csv"))
     j = os.path.join(src, f"bench_{name}.json")
