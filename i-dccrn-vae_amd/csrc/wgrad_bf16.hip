@@ -41,8 +41,7 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
 // D = +1 (dt0 == 0) or -1 (dt0 == -1): direction of the shifted copy of the L tile.
 // Staging goes through raw buffer loads: an invalid slot (plane or frequency row outside the tensor, column >= J) gets the
 // byte offset 0x80000000 (beyond the tensor), which the hardware answers with zeros -- no per-element masks (they were 2/3 of the 620 vector
-// instructions per step that bounded the first version at 190 TFLOP/s).  Needs J % 4 == 0 (a float4 never straddles J) and
-// tensors below 2 GB (host-checked).
+// instructions per step that bounded the first version at 190 TFLOP/s).  Needs tensors below 2 GB (host-checked).
 template <int D>
 __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
     constexpr int Q4 = BW_JT / 4;                                       // float4 slots per row
@@ -119,7 +118,21 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
             hreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Lr, (rok && eok) ? lbase[i] + ue : OOB, 0, 0));
         }
     };
-    auto store_step = [&]() {
+    auto store_step = [&](int step) {
+        // J % 4 != 0: the one float4 per row that straddles J also holds columns of the pitch padding (arbitrary bytes);
+        // only the last column tile takes this (uniform) branch
+        const int j0s = (jt0 + step / a.Fs) * BW_JT;
+        if (j0s + BW_JT > a.J && (a.J & 3)) {
+            const int jq = j0s + 4 * q;
+#pragma unroll
+            for (int c = 1; c < 4; ++c) {
+                const bool in = jq + c < a.J;
+#pragma unroll
+                for (int i = 0; i < NS4; ++i) sreg[i][c] = in ? sreg[i][c] : 0.f;
+#pragma unroll
+                for (int i = 0; i < NL4; ++i) lreg[i][c] = in ? lreg[i][c] : 0.f;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NS4; ++i) {
             const int row = (tid + i * 256) / Q4;
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
 
     if (nsteps > 0) load_step(0);
     for (int step = 0; step < nsteps; ++step) {
-        store_step();
+        store_step(step);
         __syncthreads();
         if (step + 1 < nsteps) load_step(step + 1);      // global loads fly under this step's MFMAs
         const unsigned short* Ah = &Ssm[0][wm * 64 + l31][half * 8];
@@ -244,8 +257,8 @@ extern "C" int idv_cconv2d_bwd_weight_bf16x3(const float* x, int Cx, int ci_off,
         a.dt0 = 0;
     }
     a.J = B * Tp;
-    // the buffer-load staging needs whole float4s inside J and 32-bit byte offsets; anything else: the exact-fp32 kernel
-    if ((a.J % 4) || (size_t)a.Sp * a.Fs * a.JpS * 4 >= 0x7ffffff0ull || (size_t)a.Lp * a.Fl * a.JpL * 4 >= 0x7ffffff0ull) {
+    // the buffer-load staging needs 31-bit byte offsets; larger tensors: the exact-fp32 kernel
+    if ((size_t)a.Sp * a.Fs * a.JpS * 4 >= 0x7ffffff0ull || (size_t)a.Lp * a.Fl * a.JpL * 4 >= 0x7ffffff0ull) {
         if (idv_cconv_wgrad_work_floats(transposed ? Cx : Cout, transposed ? Cout : Cx, B, Tp) > work_floats) return IDV_EINVAL;
         return idv_cconv2d_bwd_weight(x, Cx, ci_off, dy, Cout, Cin_total, transposed, tshift, Fin, B, Tp, Jp_x, Jp_dy, work,
                                       work_floats, dw_re, dw_im, stream);

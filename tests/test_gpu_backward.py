@@ -75,8 +75,8 @@ def test_conv_block_grads(ops, pm, cp, transposed, cin, cout, F, T, B, skip_c, b
 @pytest.mark.parametrize("transposed,cin,cout,F,T,B,skip_c,bn", [
     (False, 32, 64, 17, 40, 2, 0, True), (True, 64, 32, 5, 70, 2, 64, True), (True, 256, 128, 5, 37, 2, 256, True),
     (False, 128, 256, 9, 50, 3, 0, True), (True, 64, 64, 9, 33, 2, 64, False),
-    # B * (T + 1) % 4 == 0: the split-bf16 weight-gradient kernel itself (other column counts take its exact-fp32 fallback);
-    # several S / L plane tiles, a ragged last column tile, one and many frequency rows
+    # column counts B * (T + 1) that are and are not multiples of 4 (one masked float4 per row at the boundary), several
+    # S / L plane tiles, a ragged last column tile, one and many frequency rows
     (True, 64, 32, 5, 39, 2, 64, True), (False, 32, 64, 17, 39, 2, 0, True), (True, 256, 128, 5, 37, 2, 256, True),
     (False, 64, 128, 9, 47, 4, 0, False), (True, 128, 16, 3, 15, 2, 0, True),
 ])
