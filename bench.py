@@ -271,6 +271,8 @@ def kernel_name(cfg_id):
         return "void (anonymous namespace)::wgrad_bf16_kernel(WgradArgs) + wgrad_unpack_conv_kernel"
     if cfg_id in (-99, -98):
         return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
+    if cfg_id == 1000001:
+        return "void (anonymous namespace)::ctconv_c1_f32_kernel<false>(CgemmArgs, int)"
     if cfg_id > 0:
         d = str(cfg_id)
         mode, t = (1 if len(d) == 7 else 0), d[-6:]

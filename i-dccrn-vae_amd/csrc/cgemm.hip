@@ -1,6 +1,9 @@
 // Host-side configuration choice + launch of cgemm_kernel, and the C-ABI entry points built on it.
+#include <cstdlib>
 #include "cgemm.hpp"
 #include "../../include/idccrn_hip.h"
+
+int idv_launch_ctconv_c1_f32(const CgemmArgs& a, hipStream_t st);      // ctconv_c1_f32.hip
 
 namespace {
 
@@ -40,6 +43,8 @@ int launch_cfg(const CgemmArgs& a, hipStream_t st) {
 
 inline int waste(int n, int t) { return ((n + t - 1) / t) * t - n; }
 
+const bool USE_C1_F32 = [] { const char* e = getenv("IDV_C1_F32"); return !e || e[0] != '0'; }();
+
 // configuration id = the template arguments <MODE, WM, WN, MT_W, FO_T, JC_W, CCK> as decimal digits
 int conv_config(int mode, int CC, int M, int rows) {
     const bool fo5 = waste(rows, 5) <= waste(rows, 3);
@@ -72,6 +77,7 @@ extern "C" int idv_cconv_cck(int cin_used) { return ((2 * cin_used) % 4 == 0) ? 
 
 extern "C" int idv_cconv_config(int transposed, int cin_used, int Cout, int Fin) {
     const int rows = transposed ? Fin : (Fin - 1) / 2 + 1;
+    if (transposed && Cout == 1 && USE_C1_F32) return 1000001;          // ctconv_c1_f32_kernel (vector ALU)
     return conv_config(transposed ? IDV_TCONV : IDV_CONV, 2 * cin_used, 2 * Cout, rows);
 }
 
@@ -93,6 +99,8 @@ extern "C" int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     if (Jp < a.J) return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int mode = transposed ? IDV_TCONV : IDV_CONV;
+    // one output channel (last decoder block): 2 of the 32 MFMA rows would work; memory-shaped vector-ALU kernel instead
+    if (transposed && Cout == 1 && USE_C1_F32) return idv_launch_ctconv_c1_f32(a, st);
     return stats ? launch_conv<true>(a, mode, st) : launch_conv<false>(a, mode, st);
 }
 

@@ -30,7 +30,8 @@ int idv_abi_version(void);
  * wfrag for a complex conv holds  roundup(2*Cout,128)/32 * roundup(2*cin_used, cck)*5 * 64 floats. */
 int idv_cconv_cck(int cin_used);
 /* Which cgemm_kernel instantiation idv_cconv2d_fwd launches for a layer shape: the template arguments
- * <MODE, WM, WN, MT_W, FO_T, JC_W, CCK> written as decimal digits (e.g. 1221324), -1 if unsupported.
+ * <MODE, WM, WN, MT_W, FO_T, JC_W, CCK> written as decimal digits (e.g. 1221324), -1 if unsupported; 1000001 = the
+ * transposed conv with ONE output channel (last decoder block), which runs on the vector-ALU kernel of ctconv_c1_f32.hip.
  * Lets bench.py / profiles name the kernel a measured launch belongs to. */
 int idv_cconv_config(int transposed, int cin_used, int Cout, int Fin);
 

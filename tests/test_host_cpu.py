@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(amd):
         assert hasattr(lib, n), n
     assert lib.idv_abi_version() == 3          # 2: backward entry points; 3: split-image hand-over inside idv_clstm_fwd
     assert lib.idv_cconv_cck(ctypes.c_int(1)) == 2 and lib.idv_cconv_cck(ctypes.c_int(32)) == 4
-    assert lib.idv_cconv_config(ctypes.c_int(1), ctypes.c_int(64), ctypes.c_int(1), ctypes.c_int(129)) == 1141314
+    assert lib.idv_cconv_config(ctypes.c_int(1), ctypes.c_int(64), ctypes.c_int(1), ctypes.c_int(129)) == 1000001          # the one-output-channel vector-ALU kernel
     lib.idv_clstm_work_floats.restype = ctypes.c_longlong
     assert lib.idv_clstm_work_floats(ctypes.c_int(128), ctypes.c_int(2), ctypes.c_int(641), ctypes.c_int(1284)) == 24 * 641 * 2 * 128 + 4 * 2 * 128 + 8 * 128 * 1284
 
