@@ -43,7 +43,7 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
 // byte offset 0x80000000 (beyond the tensor), which the hardware answers with zeros -- no per-element masks (they were 2/3 of the 620 vector
 // instructions per step that bounded the first version at 190 TFLOP/s).  Needs tensors below 2 GB (host-checked).
 template <int D>
-__global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a) {
     constexpr int Q4 = BW_JT / 4;                                       // float4 slots per row
     constexpr int NS4 = BW_MS * Q4 / 256, NL4 = BW_LROWS * Q4 / 256;    // 4, 5
     constexpr unsigned OOB = 0x80000000u;       // beyond num_records (< 2 GB) and far from the 32-bit wrap of offset + size
@@ -73,24 +73,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
-    // per-thread constants of the staging slots: q is the same for every slot of a thread (256 % 8 == 0)
-    const int q = tid & (Q4 - 1);
-    unsigned sbase[NS4], lbase[NL4];         // byte offset of (plane, row 0 [+ kf], column 4q); OOB when the plane is padding
-    int lkf[NL4];
-#pragma unroll
-    for (int i = 0; i < NS4; ++i) {
-        const int row = (tid + i * 256) / Q4;
-        const int sp = sp0 + row;
-        sbase[i] = sp < a.Sp ? (unsigned)(((size_t)sp * a.Fs * a.JpS + 4 * q) * 4) : OOB;
-    }
-#pragma unroll
-    for (int i = 0; i < NL4; ++i) {
-        const int row = (tid + i * 256) / Q4;
-        const int pl = row / BW_KF, kf = row - pl * BW_KF;
-        const int lp = lp0 + pl;
-        lkf[i] = kf;
-        lbase[i] = lp < a.Lp ? (unsigned)((((size_t)lp * a.Fl + kf) * a.JpL + 4 * q) * 4) : OOB;
-    }
+    // staging slots: thread (r8 = tid / 8, q = tid % 8) owns float4 q of S rows r8 + 32 i (i < 4) and of the L rows
+    // (plane r8, frequency tap kf = i) (i < 5): slot offsets are affine in i, so one base register each instead of nine
+    // (with 160 accumulator registers that is what keeps the kernel under 256 and lets two workgroups share a CU: the
+    // split / pack vector work of one overlaps the MFMAs of the other)
+    const int q = tid & (Q4 - 1), r8 = tid / Q4;
+    const unsigned sbase = (unsigned)(((size_t)(sp0 + r8) * a.Fs * a.JpS + 4 * q) * 4);
+    const unsigned sstep = (unsigned)((size_t)32 * a.Fs * a.JpS * 4);
+    const bool lok = lp0 + r8 < a.Lp;
+    const unsigned lbase = (unsigned)(((size_t)(lp0 + r8) * a.Fl * a.JpL + 4 * q) * 4);
+    const unsigned lstep = (unsigned)((size_t)a.JpL * 4);
     const bool edge_lane = D > 0 ? (q == Q4 - 1) : (q == 0);
 
     f32x4 sreg[NS4], lreg[NL4];
@@ -103,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
         const unsigned us = (unsigned)(((long long)fs * a.JpS + j0) * 4);
 #pragma unroll
         for (int i = 0; i < NS4; ++i) {
-            const unsigned off = (colok && sbase[i] != OOB) ? sbase[i] + us : OOB;
+            const unsigned off = (colok && sp0 + r8 + 32 * i < a.Sp) ? sbase + i * sstep + us : OOB;
             sreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(Sr, off, 0, 0));
         }
         const unsigned ul = (unsigned)(((long long)(2 * fs - 2) * a.JpL + j0) * 4);     // wraps for fs = 0: only used when valid
@@ -112,10 +104,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
         const unsigned ue = (unsigned)(((long long)(2 * fs - 2) * a.JpL + je - 4 * q) * 4);
 #pragma unroll
         for (int i = 0; i < NL4; ++i) {
-            const int fl = 2 * fs + lkf[i] - 2;
-            const bool rok = lbase[i] != OOB && fl >= 0 && fl < a.Fl;
-            lreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(Lr, (rok && colok) ? lbase[i] + ul : OOB, 0, 0));
-            hreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Lr, (rok && eok) ? lbase[i] + ue : OOB, 0, 0));
+            const int fl = 2 * fs + i - 2;
+            const bool rok = lok && fl >= 0 && fl < a.Fl;
+            lreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(Lr, (rok && colok) ? lbase + i * lstep + ul : OOB, 0, 0));
+            hreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Lr, (rok && eok) ? lbase + i * lstep + ue : OOB, 0, 0));
         }
     };
     auto store_step = [&](int step) {
@@ -135,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NS4; ++i) {
-            const int row = (tid + i * 256) / Q4;
+            const int row = r8 + 32 * i;
             uint2 hi, lo;
             split4(sreg[i][0], sreg[i][1], sreg[i][2], sreg[i][3], hi, lo);
             *(uint2*)&Ssm[0][row][4 * q] = hi;
@@ -143,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NL4; ++i) {
-            const int row = (tid + i * 256) / Q4;
+            const int row = r8 * BW_KF + i;                      // LDS row = plane * 5 + kf (what the B-fragment reads expect)
             const f32x4 v = lreg[i];
             // shifted copy: columns j+D .. j+D+3 = own elements + the neighbour slot's edge element (lanes +-1 hold the
             // neighbouring float4 of the same row: DPP row shift; at the row ends the separately loaded edge element)
