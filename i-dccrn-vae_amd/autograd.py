@@ -239,10 +239,10 @@ class LstmFn(torch.autograd.Function):
         out = Planar.empty(H, 1, x.B, x.T, x.Tp, xbuf.device)
         nwork = ops._ll_fn("idv_clstm_train_work_floats")(i(H), i(x.B), i(x.T), i(x.Jp))
         work = torch.empty(int(nwork), dtype=torch.float32, device=xbuf.device)
-        # bf16x3 training mode: the persistent split-bf16 recurrence (H = 384 / 768) also saves the gates and cell states
-        # the fp32 BPTT kernels read; every other size keeps the exact-fp32 per-step recurrence
+        # bf16x3 training mode: the split-bf16 recurrences (H = 128 register-resident, H = 384 / 768 persistent cooperative)
+        # also save the gates and cell states the fp32 BPTT kernels read; every other size keeps the exact-fp32 recurrence
         flags = 4
-        if ops.PRECISION == "bf16x3" and ops.LSTM_PERSISTENT and L.lib().idv_lstm_pers_supported(i(H), i(x.B)):
+        if ops.PRECISION == "bf16x3" and (H == 128 or (ops.LSTM_PERSISTENT and L.lib().idv_lstm_pers_supported(i(H), i(x.B)))):
             flags |= 1
         call("idv_clstm_fwd", x.ptr(), i(K), p(p0[0]), p(p0[1]), p(p0[2]), p(p1[0]), p(p1[1]), p(p1[2]), i(H), i(x.B), i(x.T),
              i(x.Tp), i(x.Jp), p(work), out.ptr(), i(flags), p(None), stream_ptr())

@@ -195,6 +195,8 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bf16_kernel(const RecArgs a) 
     // bf16 fragments follow the fp32 ones in the packed blob: [set][tile][kb][split][lane] x 16 B
     const uint4* wb = (const uint4*)(a.whh + (size_t)2 * 4 * H * H) + (size_t)s * 32 * 4 * 2 * 64 + lane;
     float* hout = a.hout + (size_t)run * a.T * a.B * H;
+    float* gsv = a.gsave ? a.gsave + z * a.g_run_z + s * a.g_run_s : nullptr;      // training: as lstm_rec_kernel
+    float* csv = a.csave ? a.csave + (size_t)run * a.T * a.B * H : nullptr;
 
     for (int e = tid; e < 2 * 2 * 16 * H / 2; e += 256) ((unsigned*)hs)[e] = 0u;
 
@@ -272,7 +274,14 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bf16_kernel(const RecArgs a) 
                 creg[u][r] = cn;
                 const float hv = og * tanhf_(cn);
                 const int row = rq * 4 + r;
-                if (b0 + row < a.B) hout[(rowbase + row) * H + unit] = hv;
+                if (b0 + row < a.B) {
+                    hout[(rowbase + row) * H + unit] = hv;
+                    if (gsv) {
+                        float* gp = gsv + (rowbase + row) * a.ldg + ((wave + 4 * u) * 4) * 16 + col;
+                        gp[0] = ig; gp[16] = fg; gp[32] = gv; gp[48] = og;
+                        csv[(rowbase + row) * H + unit] = cn;
+                    }
+                }
                 const __bf16 hh = (__bf16)hv;
                 const __bf16 hl = (__bf16)(hv - (float)hh);
                 const int o = row * H + ((((unit >> 3) ^ row) & 15) << 3) + (unit & 7);
@@ -637,9 +646,9 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     hipStream_t st = (hipStream_t)stream;
     const long long TB = (long long)T * B;
     const bool save = (flags & 4) != 0;
-    // training forward in split-bf16 mode: only where the persistent recurrence exists (H = 384 / 768); H = 128 and the
-    // generic sizes keep the exact-fp32 recurrence
-    if (save && (flags & 1) && ((flags & 8) || !idv_lstm_pers_supported(H, B))) return IDV_EINVAL;
+    // training forward in split-bf16 mode: where a split-bf16 recurrence exists (H = 128: register-resident kernel;
+    // H = 384 / 768: the persistent cooperative kernel); the generic sizes keep the exact-fp32 recurrence
+    if (save && (flags & 1) && H != 128 && ((flags & 8) || !idv_lstm_pers_supported(H, B))) return IDV_EINVAL;
     float* G = work;                       // [2][TB][8H]  then (inference: same memory)  [4][TB][4H]
     float* G1 = save ? work + 16 * TB * H : work;
     float* h0 = (save ? G1 : work) + 16 * TB * H;        // [4][TB][H]

@@ -167,10 +167,11 @@ def test_clstm_grads(ops, cp, H, I, T, B):
     _clstm_grads(ops, cp, H, I, T, B, 2e-5, GTOL)
 
 
-@pytest.mark.parametrize("H,I,T,B", [(384, 64, 9, 3), (768, 128, 7, 20), (384, 1280, 33, 32)])
+@pytest.mark.parametrize("H,I,T,B", [(384, 64, 9, 3), (768, 128, 7, 20), (384, 1280, 33, 32), (128, 1280, 25, 19)])
 def test_clstm_grads_bf16x3(ops, cp, H, I, T, B):
-    """bf16x3 training mode at the VAE encoders' hidden sizes: the forward recurrence is the persistent split-bf16 kernel,
-    which also leaves the activated gates and cell states for the fp32 BPTT kernels (1, 2 and 4 row tiles per workgroup)."""
+    """bf16x3 training mode: the forward recurrence is a split-bf16 kernel (H = 384 / 768: persistent cooperative, 1, 2 and 4
+    row tiles per workgroup; H = 128: register-resident), which also leaves the activated gates and cell states for the fp32
+    BPTT kernels."""
     keep = ops.PRECISION
     ops.set_precision("bf16x3")
     try:
