@@ -336,6 +336,36 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
     return r
 
 
+def two_stream_probe(step, steps, ops, utt_per_step, batch):
+    """Two HIP streams (sub-batch pipelining, opt-in via IDV_STREAM_SPLIT=2): throughput + ONE bit-exactness check of its
+    output against the one-stream output of the same input.  Leaves ops.STREAM_SPLIT as it found it."""
+    import torch
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    probe = {}
+    orig_forward = pm.DCCRN_.forward
+    keep = ops.STREAM_SPLIT
+
+    def spy(self, signal, train=True):
+        r = orig_forward(self, signal, train)
+        probe["est"] = r[0]
+        return r
+    pm.DCCRN_.forward = spy
+    try:
+        ops.STREAM_SPLIT = 1
+        step()
+        one = probe["est"].clone()
+        ops.STREAM_SPLIT = 2
+        step()
+        b_el, _, _ = timed(step, steps, ops)
+        torch.cuda.synchronize()
+        return {"two_stream": {"value": round(utt_per_step * steps / b_el, 3), "ms_per_step": round(b_el / steps * 1e3, 3),
+                               "streams": ops.stream_split(batch)},
+                "bit_exact": bool(torch.equal(one, probe["est"]))}
+    finally:
+        pm.DCCRN_.forward = orig_forward
+        ops.STREAM_SPLIT = keep
+
+
 def timed(step, steps, ops, barrier=None):
     import torch
     ops.LAUNCH_LOG = []
@@ -427,6 +457,12 @@ def main():
         roofline["note"] = (f"timed region ran {n_streams} sub-batch streams (IDV_STREAM_SPLIT): event intervals include CU "
                             "time-slicing with the other stream")
 
+    # ---- informational: the same fp32 workload with the opt-in two-stream sub-batch split (never `value`), checked bit for bit
+    two_f32 = None
+    if (world == 1 and not args.no_alt and args.workload == "dccrn_cl" and args.precision == "fp32" and n_streams == 1):
+        two_f32 = two_stream_probe(step, args.steps, ops, utt_per_step, args.batch)
+        log(f"fp32 two-stream (opt-in): {two_f32}")
+
     # ---- secondary record: the split-bf16 mode on the same workload (narrower arithmetic than the reference: never `value`)
     alt = None
     if (world == 1 and not args.no_alt and args.workload == "dccrn_cl" and args.precision == "fp32"):
@@ -442,29 +478,8 @@ def main():
                    "value": round(utt_per_step * args.steps / a_el, 3), "unit": "utterances/sec",
                    "ms_per_step": round(a_el / args.steps * 1e3, 3), "streams": 1, "loss": float(a_last),
                    "roofline": roofline_of(a_launch, args.steps, a_el / args.steps, "bf16x3", args.batch, args.workload)}
-            # two HIP streams (sub-batch pipelining, opt-in via IDV_STREAM_SPLIT=2): throughput + ONE bit-exactness check of
-            # its output against the one-stream output of the same input
-            pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
-            probe = {}
-            orig_forward = pm.DCCRN_.forward
-
-            def spy(self, signal, train=True):
-                r = orig_forward(self, signal, train)
-                probe["est"] = r[0]
-                return r
-            pm.DCCRN_.forward = spy
-            try:
-                step()
-                one = probe["est"].clone()
-                ops.STREAM_SPLIT = 2
-                step()
-                b_el, _, _ = timed(step, args.steps, ops)
-                torch.cuda.synchronize()
-                alt["two_stream"] = {"value": round(utt_per_step * args.steps / b_el, 3), "ms_per_step": round(b_el / args.steps * 1e3, 3),
-                                     "streams": ops.stream_split(args.batch)}
-                alt["two_stream_bit_exact"] = bool(torch.equal(one, probe["est"]))
-            finally:
-                pm.DCCRN_.forward = orig_forward
+            ts = two_stream_probe(step, args.steps, ops, utt_per_step, args.batch)
+            alt["two_stream"], alt["two_stream_bit_exact"] = ts["two_stream"], ts["bit_exact"]
         finally:
             ops.STREAM_SPLIT = keep_split
             ops.set_precision(args.precision)
@@ -484,6 +499,9 @@ def main():
                            streams=n_streams, loss=loss_val, input=("streamed from the host per step" if args.stream else "resident in HBM")),
             "roofline": roofline,
         }
+        if two_f32 is not None:
+            out["two_stream"] = dict(two_f32["two_stream"], bit_exact=two_f32["bit_exact"],
+                                     note="opt-in IDV_STREAM_SPLIT=2 (DESIGN.md 5.1); `value` is the one-stream default")
         if alt is not None:
             out["alt"] = alt
         if world == 1 and not args.no_cpu_baseline and args.workload in ("dccrn_cl", "dccrn_cl_train"):
