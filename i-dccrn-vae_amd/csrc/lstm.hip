@@ -601,6 +601,10 @@ int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
     }
     if (ra.H == 128 && (flags & 1)) {
         hipLaunchKernelGGL(lstm_rec_bf16_kernel, grid, dim3(256), 0, st, ra);
+    } else if (ra.H == 128 && cstate && !(flags & 8) && idv_lstm_coop_f32_supported(ra.H, ra.B)) {
+        // exact fp32 on four CUs per sequence tile (lstm_coop_f32.hip); flags bit 3 keeps the one-CU register-resident kernel
+        return idv_lstm_rec_coop_f32(ra.g, ra.g_run_z, ra.g_run_s, ra.ldg, ra.whh, ra.hout, ra.H, ra.B, ra.T,
+                                     (void*)(cstate + 4LL * ra.B * ra.H), ra.gsave, ra.csave, (void*)st);
     } else if (ra.H == 128) {
         const size_t smem = (size_t)2 * 128 * 16 * sizeof(float);
         hipLaunchKernelGGL(lstm_rec_kernel<true>, grid, dim3(256), smem, st, ra);

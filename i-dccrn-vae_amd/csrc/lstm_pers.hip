@@ -329,6 +329,28 @@ static std::mutex g_pers_mu;
 static hipEvent_t g_pers_done[16] = {};
 static hipStream_t g_pers_stream[16] = {};
 
+// begin: take the chain lock and make `st` wait for the previous cooperative launch of this device; end: record + release
+int idv_coop_chain_begin(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return IDV_ELAUNCH;
+    g_pers_mu.lock();
+    if (g_pers_done[dev] && g_pers_stream[dev] != st && hipStreamWaitEvent(st, g_pers_done[dev], 0) != hipSuccess) {
+        g_pers_mu.unlock();
+        return IDV_ELAUNCH;
+    }
+    return IDV_OK;
+}
+int idv_coop_chain_end(hipStream_t st) {
+    int dev = 0;
+    int rc = IDV_OK;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) rc = IDV_ELAUNCH;
+    if (!rc && !g_pers_done[dev] && hipEventCreateWithFlags(&g_pers_done[dev], hipEventDisableTiming) != hipSuccess) rc = IDV_ELAUNCH;
+    if (!rc && hipEventRecord(g_pers_done[dev], st) != hipSuccess) rc = IDV_ELAUNCH;
+    if (!rc) g_pers_stream[dev] = st;
+    g_pers_mu.unlock();
+    return rc;
+}
+
 static unsigned long long* g_prof = nullptr;
 
 // diagnostic: while a device buffer of 256 x 8 counters is registered, idv_lstm_rec_pers launches the instrumented twin of
@@ -390,18 +412,14 @@ extern "C" int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_
             return IDV_ELAUNCH;                                                                                           \
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, a);                                                              \
     } while (0)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return IDV_ELAUNCH;
-    std::lock_guard<std::mutex> lock(g_pers_mu);
-    if (g_pers_done[dev] && g_pers_stream[dev] != st && hipStreamWaitEvent(st, g_pers_done[dev], 0) != hipSuccess) return IDV_ELAUNCH;
+    int rc = idv_coop_chain_begin(st);
+    if (rc) return rc;
     if (H == 384) {
         if (nrt == 1) IDV_PERS_LAUNCH(3, 1); else if (nrt == 2) IDV_PERS_LAUNCH(3, 2); else IDV_PERS_LAUNCH(3, 4);
     } else {
         if (nrt == 1) IDV_PERS_LAUNCH(6, 1); else if (nrt == 2) IDV_PERS_LAUNCH(6, 2); else IDV_PERS_LAUNCH(6, 4);
     }
 #undef IDV_PERS_LAUNCH
-    if (!g_pers_done[dev] && hipEventCreateWithFlags(&g_pers_done[dev], hipEventDisableTiming) != hipSuccess) return IDV_ELAUNCH;
-    if (hipEventRecord(g_pers_done[dev], st) != hipSuccess) return IDV_ELAUNCH;
-    g_pers_stream[dev] = st;
+    if ((rc = idv_coop_chain_end(st))) return rc;
     return idv_launch_status();
 }

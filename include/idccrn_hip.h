@@ -207,6 +207,14 @@ int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_run_s, int 
  * idv_pack_lstm_ih.  Needs 4H % 256 == 0 and H % 64 == 0. */
 int idv_lstm_proj1_bf16x3(const void* himg, long long lo_off_slots, const void* wfrag_bf16, const float* bias, float* G1, int H,
                           int B, int T, int Tp, int Jp, void* stream);
+/* The H = 128 recurrence (DCCRN-CL bottleneck) in exact fp32 on FOUR CUs per (run, 16-sequence tile) with the same hand-off
+ * (lstm_coop_f32.hip): idv_clstm_fwd uses it in fp32 mode when idv_lstm_coop_f32_supported (H == 128, 16 * ceil(B/16) <= 240
+ * workgroups; IDV_LSTM_COOP_F32=0 or flags bit 3 keep the one-CU register-resident kernel).  hout required; gsave (== g) /
+ * csave as above; work: idv_lstm_coop_f32_work_bytes(H, B) bytes, 16-byte aligned. */
+int idv_lstm_coop_f32_supported(int H, int B);
+long long idv_lstm_coop_f32_work_bytes(int H, int B);
+int idv_lstm_rec_coop_f32(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh_frag, float* hout, int H,
+                          int B, int T, void* work, float* gsave, float* csave, void* stream);
 /* diagnostic (not part of the drop-in boundary): while a device buffer of 256 x 8 counters is registered, idv_lstm_rec_pers runs
  * an instrumented twin in which every workgroup accumulates core-clock cycles per phase (spin, -, barrier, loads + MFMA,
  * reduce + cell, drain + barrier, -, XCC id); NULL restores the production kernel.  tests/tools/lstm_phase_probe.py */
