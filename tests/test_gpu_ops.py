@@ -299,6 +299,41 @@ def test_clstm_persistent_matches_per_step(ops, H, B, T):
     assert relerr(got.cpu(), ref.cpu()) < 2e-4
 
 
+@pytest.mark.parametrize("B,T", [(5, 40), (40, 33), (64, 641)])
+def test_clstm_coop_f32_matches_one_cu(ops, B, T):
+    """The exact-fp32 H = 128 recurrence spread over four CUs per sequence tile (lstm_coop_f32.hip: gate columns split over
+    workgroups, h exchanged through global memory) against the one-CU register-resident kernel on the same inputs: same
+    products, another summation order -> 1e-6; ragged last tile; bit-repeatable; the full 641-frame length."""
+    H, I = 128, 64
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(T, B, I, 2, generator=g) * 0.5
+    names = [f"lstm_{s}.{w}_l{l}" for s in ("re", "im") for l in (0, 1) for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    sd = {}
+    for n in names:
+        l = int(n[-1])
+        shape = (4 * H, I if l == 0 else H) if "weight_ih" in n else ((4 * H, H) if "weight_hh" in n else (4 * H,))
+        sd[n] = O.synth_tensor(n, shape, 93) * (2.0 if "weight" in n else 1.0)
+    xp = ops.Planar.from_tensor5(x.permute(1, 2, 0, 3).unsqueeze(2).cuda())
+    get = lambda n: sd[n].cuda()
+    keep = (ops.PRECISION, ops.LSTM_PERSISTENT)
+    try:
+        ops.set_precision("fp32")
+        p0, p1 = ops.pack_lstm(get, H, I, 0, "cuda"), ops.pack_lstm(get, H, H, 1, "cuda")
+        ops.LSTM_PERSISTENT = False                                  # flags bit 3: the one-CU kernel
+        ref = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
+        ops.LSTM_PERSISTENT = True
+        assert amd_lib().idv_lstm_coop_f32_supported(H, B)
+        got = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
+        got2 = ops.clstm(xp, p0, p1, H).channel_slice(0, H)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(keep[0])
+        ops.LSTM_PERSISTENT = keep[1]
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, got2)
+    assert relerr(got.cpu(), ref.cpu()) < 1e-6
+
+
 def amd_lib():
     import importlib
     return importlib.import_module("i-dccrn-vae_amd")._lib.lib()
