@@ -15,6 +15,10 @@ __global__ void planar_to_image_kernel(const float* __restrict__ x, int C, int F
     const long long n = (long long)((2 * C + 7) / 8) * F * Jp;
     if (blockIdx.x == 0 && threadIdx.x < 2)
         *(uint4*)(img + IDV_IMG_ZSLOT * 8 + (threadIdx.x ? lo_off : 0)) = make_uint4(0u, 0u, 0u, 0u);
+    // 8 zero slots behind each plane: a consumer with time taps (x[t], x[t+1]) (the data-gradient form, tshift 0) reads
+    // column J of the last row, which is the slot behind the plane when the pitch has no padding (Jp == J)
+    if (blockIdx.x == 0 && threadIdx.x >= 32 && threadIdx.x < 48)
+        *(uint4*)(img + (n + (threadIdx.x & 7)) * 8 + ((threadIdx.x & 8) ? lo_off : 0)) = make_uint4(0u, 0u, 0u, 0u);
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(idx % Jp);
         const long long t = idx / Jp;

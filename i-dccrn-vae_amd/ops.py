@@ -97,6 +97,7 @@ class Planar:
 
 IMG_SLACK = 4096          # bf16 elements kept readable before, between and after the two planes of an Image
 IMAGE_PATH = os.environ.get("IDV_IMAGE_PATH", "1") != "0"     # eval bf16x3: keep inter-layer activations as split images
+IMAGE_TRAIN = os.environ.get("IDV_IMAGE_TRAIN", "1") != "0"   # bf16x3 training: feed the conv kernels split images too
 
 
 class Image:
@@ -402,15 +403,19 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
 
 
 def cconv2d_img(x, wfrag_bf16, bias, cout: int, *, transposed=False, causal=True, slope=None, skip=None,
-                want_planar=False, want_image=True):
+                want_planar=False, want_image=True, adjoint=False):
     """Eval-mode conv / transposed conv on the split-bf16 path with image and/or planar sources (x and skip must share
-    one format) -> (Planar or None, Image or None)."""
+    one format) -> (Planar or None, Image or None).  adjoint: the data-gradient form (time taps reversed, all T frames kept,
+    see cconv_dgrad)."""
     src_img = isinstance(x, Image)
     if skip is not None and isinstance(skip, Image) != src_img:
         raise RuntimeError("cconv2d_img: x and skip must have the same format")
     Fout = 2 * x.F - 1 if transposed else (x.F - 1) // 2 + 1
     t_out = x.T if causal else (x.T + 1 if transposed else x.T - 1)
     tshift = -1 if (causal or transposed) else 0
+    if adjoint:
+        assert causal
+        tshift, t_out = 0, x.T
     dev = x.buf.device
     outp = Planar.empty(cout, Fout, x.B, t_out, x.Tp, dev) if want_planar else None
     outi = Image.empty(cout, Fout, x.B, t_out, x.Tp, dev) if want_image else None
