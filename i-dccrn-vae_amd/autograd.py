@@ -66,8 +66,14 @@ class ConvBlockFn(torch.autograd.Function):
             wbf = conv.packed_bf16(None, cin_used)
         if bn is not None:
             stats = torch.zeros(cout, 5, dtype=torch.float64, device=dev)
-            y = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, stats=stats,
-                            wfrag_bf16=wbf)
+            if wbf is not None and ops.IMAGE_TRAIN and x.Jp == (skip.Jp if skip is not None else x.Jp):
+                # split images of the sources (made once per activation: an encoder output feeds the next block AND, as
+                # skip, a decoder block): the image-source kernel stages by LDS-DMA, 1.5x the planar-source one
+                y = ops.cconv2d_img_train(_image_of(xbuf, x), wbf, bias, cout, stats, transposed=conv._transposed,
+                                          skip=_image_of(skipbuf, skip) if skip is not None else None)
+            else:
+                y = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, stats=stats,
+                                wfrag_bf16=wbf)
             first = bool(bn.init_flag)
             moments, fold = ops.cbn_finalize(stats, float(y.B) * y.F * y.T, bn, first, bn.momentum)
             bn._stats_gen += 1
@@ -143,6 +149,15 @@ def _dgrad(dy: Planar, w_re, w_im, cout_adj: int, cin_adj: int, fwd_transposed: 
         return ops.cconv_dgrad(dy, None, zb, cout_adj, fwd_transposed, True, wfrag_bf16=w16)
     wf, bz = ops.pack_cconv_adjoint(w_re, w_im, cout_adj, cin_adj, cin_adj, adj_tr)
     return ops.cconv_dgrad(dy, wf, bz, cout_adj, fwd_transposed, True)
+
+
+def _image_of(buf: torch.Tensor, pl: Planar):
+    """Split image of an activation, cached on its buffer tensor (same lifetime as the activation itself)."""
+    img = getattr(buf, "_idv_img", None)
+    if img is None or img.Jp != pl.Jp or img.C != pl.C or img.F != pl.F:
+        img = ops.to_image(pl)
+        buf._idv_img = img
+    return img
 
 
 def _dy_image(dy: Planar, cin_adj: int):

@@ -699,3 +699,38 @@ extern "C" int idv_cconv2d_img_fwd(int src_is_image, const void* x0_img, long lo
     }
     return IDV_EINVAL;
 }
+
+// Training forward from split images: idv_cconv2d_img_fwd with the train-mode moments epilogue (planar fp32 output y, the
+// five per-channel sums the batch statistics need) -- what the bf16x3 training mode runs instead of the planar-source
+// idv_cconv2d_bf16x3_fwd, whose staging splits the fp32 patch in registers (1.5x slower).  One row tile per wave (the
+// two-tile form keeps no registers for the moments).
+extern "C" int idv_cconv2d_img_train_fwd(const void* x0_img, long long lo_off0, int C0, const void* x1_img, long long lo_off1, int C1,
+                                         const void* wfrag_bf16, const float* bias, float* out_planar, double* stats, int transposed,
+                                         int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream) {
+    if (!x0_img || !wfrag_bf16 || !bias || !out_planar || !stats || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1)
+        return IDV_EINVAL;
+    if (!idv_cconv_bf16_supported(transposed, C0, C1, 1, Cout)) return IDV_EINVAL;
+    if (C1 > 0 && (!x1_img || (reinterpret_cast<uintptr_t>(x1_img) & 15))) return IDV_EINVAL;
+    if (reinterpret_cast<uintptr_t>(x0_img) & 15) return IDV_EINVAL;
+    CgemmArgs a{};
+    a.x0 = (const float*)x0_img; a.x1 = (const float*)x1_img; a.C0 = C0; a.C1 = C1;
+    a.lo_off0 = lo_off0; a.lo_off1 = lo_off1;
+    a.Fin = Fin;
+    a.Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.Jp1 = Jp; a.x1_div = 1;
+    a.wfrag = (const float*)wfrag_bf16; a.bias = bias; a.slope = nullptr; a.out = out_planar;
+    a.out_img = nullptr; a.out_lo_off = 0;
+    a.M = 2 * Cout; a.Mtiles = (a.M + 31) / 32; a.cplx_rows = 1; a.Cout = Cout;
+    a.tshift = -1; a.t_valid = t_valid_out; a.stats = stats; a.ldo = 0; a.nB = B;
+    if (Jp < a.J || (long long)((2 * (C0 > C1 ? C0 : C1) + 7) / 8) * Fin * Jp > 0x7fffff00LL) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = transposed ? Fin : a.Fout;
+    const bool fo5 = waste(rows, 5) <= waste(rows, 3);
+    const bool wide = a.M >= 128;
+    if (!transposed) {
+        if (wide) return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 1, true, 1, true, IDV_AD>(a, st);
+        return fo5 ? launch_bf16<IDV_CONV, 2, 2, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_CONV, 2, 2, 3, 1, true, 1, true, IDV_AD>(a, st);
+    }
+    if (wide) return fo5 ? launch_bf16<IDV_TCONV, 4, 1, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_TCONV, 4, 1, 3, 2, true, 1, true, IDV_AD>(a, st);
+    return fo5 ? launch_bf16<IDV_TCONV, 2, 2, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_TCONV, 2, 2, 3, 1, true, 1, true, IDV_AD>(a, st);
+}

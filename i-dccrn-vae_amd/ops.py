@@ -438,6 +438,25 @@ def cconv2d_img(x, wfrag_bf16, bias, cout: int, *, transposed=False, causal=True
     return outp, outi
 
 
+def cconv2d_img_train(x: Image, wfrag_bf16, bias, cout: int, stats, *, transposed=False, skip: Optional[Image] = None) -> Planar:
+    """Training forward of a causal conv block from split images: planar fp32 y + the batch-norm moments (`stats`)."""
+    Fout = 2 * x.F - 1 if transposed else (x.F - 1) // 2 + 1
+    out = Planar.empty(cout, Fout, x.B, x.T, x.Tp, x.buf.device)
+    c1 = skip.C if skip is not None else 0
+    if LAUNCH_LOG is not None:
+        cfg = -(100000000 + L.lib().idv_cconv_img_config(i(1), i(1 if transposed else 0), i(x.C + c1), i(cout), i(x.F)))
+        macs = 4 * (x.C + c1) * cout * 10 * x.B * x.T * (x.F if transposed else Fout)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    call("idv_cconv2d_img_train_fwd", x.ptr(), ll(x.lo_slots), i(x.C), skip.ptr() if skip is not None else p(None),
+         ll(skip.lo_slots if skip is not None else 0), i(c1), p(wfrag_bf16), p(bias), out.ptr(), p(stats),
+         i(1 if transposed else 0), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(x.T), stream_ptr())
+    if LAUNCH_LOG is not None:
+        ev1.record()
+        LAUNCH_LOG.append((cfg, macs, ev0, ev1))
+    return out
+
+
 def pw_gemm(x_ptr, K: int, wfrag, bias, M: int, B: int, Tp: int, Jp: int, t_valid: int, out_ptr, *, slope=None,
             swap=False, ldo=0):
     call("idv_pw_gemm", x_ptr, i(K), p(wfrag), p(bias), p(slope), out_ptr, i(M), i(B), i(Tp), i(Jp), i(t_valid),

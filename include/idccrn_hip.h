@@ -114,6 +114,11 @@ int idv_cconv2d_fwd_img(const float* x0, int C0, const float* x1, int C1, int Jp
                         const float* prelu_slope, float* out_planar, void* out_img, long long out_lo_off_elems,
                         int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out,
                         void* stream);   /* exact-fp32 idv_cconv2d_fwd (eval, x1_div 1) writing planar and/or image */
+/* training forward from split images (bf16x3 training mode): planar fp32 y + the per-channel moments, as idv_cconv2d_fwd with
+ * `stats`; sources as idv_cconv2d_img_fwd with src_is_image = 1 */
+int idv_cconv2d_img_train_fwd(const void* x0_img, long long lo_off0, int C0, const void* x1_img, long long lo_off1, int C1,
+                              const void* wfrag_bf16, const float* bias, float* out_planar, double* stats, int transposed, int Cout,
+                              int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
 int idv_cconv_img_config(int src_is_image, int transposed, int Cin, int Cout, int Fin);   /* template digits <MODE, WM, WN,
                         FO_T, JC_W, MT_W, IMGIN, AD> of the cgemm_bf16_kernel idv_cconv2d_img_fwd launches (profiles) */
 int idv_planar_to_image(const float* x, int C, int F, int J, int Jp, void* img, long long lo_off_elems, void* stream);
