@@ -106,8 +106,15 @@ class ConvBlockFn(torch.autograd.Function):
             grads_bn = (dgrr, dgri, dgii, dbr, dbi, dslope.reshape(slope.shape) if slope is not None else None)
         else:
             dy = dz
-        # bias and weight gradients
-        db_re, db_im = ops.cconv_bias_grad(dy)
+        # bias and weight gradients.  A conv bias in front of a batch norm has an exactly zero gradient: the backward of the
+        # normalisation makes every channel of dy sum to zero over the batch (sum dy = Z^T sum du + A sum (y - mu) + N c with
+        # sum (y - mu) = 0 and c = -Z^T sum du / N, cbn_bwd_finalize); what autograd returns there in the reference is
+        # rounding noise far below the weight-decay term of its Adam step.  No pass over dy for it.
+        if bn is not None:
+            db_re = torch.zeros(cout, dtype=torch.float32, device=dzbuf.device)
+            db_im = torch.zeros_like(db_re)
+        else:
+            db_re, db_im = ops.cconv_bias_grad(dy)
         cin_total = w_re.shape[0] if tr else w_re.shape[1]
         used = x.C + (skip.C if skip is not None else 0)
         mk = torch.zeros_like if used < cin_total else torch.empty_like
