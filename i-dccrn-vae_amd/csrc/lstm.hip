@@ -632,13 +632,28 @@ int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
 
 }  // namespace
 
+// floats of the scratch region behind cstate: the planar transpose of h0 (per-step paths) or the exchange buffer + arrive
+// counters of a cooperative recurrence (whose size does not shrink with T: for short inputs it is the larger one)
+static long long hp_floats(int H, int B, int Jp) {
+    long long n = 4LL * H * Jp;
+    if (idv_lstm_pers_supported(H, B)) {
+        const long long m = (idv_lstm_pers_work_bytes(H, B) + 3) / 4;
+        if (m > n) n = m;
+    }
+    if (idv_lstm_coop_f32_supported(H, B)) {
+        const long long m = (idv_lstm_coop_f32_work_bytes(H, B) + 3) / 4;
+        if (m > n) n = m;
+    }
+    return (n + 63) / 64 * 64;
+}
+
 extern "C" long long idv_clstm_work_floats(int H, int B, int T, int Jp) {
-    return 24LL * T * B * H + 4LL * B * H + 8LL * H * Jp;      // [G | h0 | h1 | cstate | hp / exchange | split image of h0]
+    return 24LL * T * B * H + 4LL * B * H + hp_floats(H, B, Jp) + 4LL * H * Jp;   // [G | h0 | h1 | cstate | hp / exchange | split image of h0]
 }
 // training (flags bit 2): both layers' gate buffers and the cell states are kept for the backward pass
 //   [G0 16TBH | G1 16TBH | h0 4TBH | h1 4TBH | c0 4TBH | c1 4TBH | cstate 4BH | hp 4*H*Jp]
 extern "C" long long idv_clstm_train_work_floats(int H, int B, int T, int Jp) {
-    return 48LL * T * B * H + 4LL * B * H + 4LL * H * Jp;
+    return 48LL * T * B * H + 4LL * B * H + hp_floats(H, B, Jp);
 }
 
 extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
@@ -673,7 +688,7 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     const bool img1 = (flags & 1) && !(flags & 8) && !save && wih1_bf16 && idv_lstm_pers_supported(H, B) &&
                       idv_lstm_proj_bf16_supported(H, H) && (4 * H) % 256 == 0;
     float* hp = cstate + 4LL * B * H;                  // [4 runs][H][Jp] (per-step path) / exchange buffer (persistent path)
-    void* himg = (void*)(hp + 4LL * H * Jp);           // [hi | lo][4 runs][H/8][Jp] x 16 B
+    void* himg = (void*)(hp + hp_floats(H, B, Jp));    // [hi | lo][4 runs][H/8][Jp] x 16 B
     const long long himg_lo = 4LL * (H / 8) * Jp;
     RecArgs r0{G, TB * 8 * H, 4LL * H, 8 * H, whh0, h0, H, B, T, save ? G : nullptr, c0, img1 ? himg : nullptr, himg_lo, Tp, Jp};
     if ((rc = launch_rec(r0, cstate, flags, st))) return rc;

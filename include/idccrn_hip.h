@@ -192,7 +192,7 @@ int idv_planar_to_complex(const float* act, float* out_c, int F, int B, int T, i
 /* ComplexLSTM.forward (complex_progress.py:50-74): four 2-layer LSTM passes, real = rr - ii,
  * imag = ir + ri.  x: planar [2][K][Jp]; out: planar [2][H][Jp].  flags bit 0: split-bf16 recurrence (H = 128).  wihN / bihN: idv_pack_lstm_ih of layer
  * N, whhN: idv_pack_lstm_hh of layer N.  work: idv_clstm_work_floats(H, B, T, Jp) floats. */
-long long idv_clstm_work_floats(int H, int B, int T, int Jp);   /* 24*T*B*H + 4*B*H + 8*H*Jp */
+long long idv_clstm_work_floats(int H, int B, int T, int Jp);   /* 24*T*B*H + 4*B*H + scratch(H, B, Jp) + 4*H*Jp */
 /* Persistent cooperative recurrence of one layer for H = 384 / 768 (the VAE encoders' 3*zdim / 6*zdim, reference
  * model/pvae_module.py:1819, :2160-2163), split-bf16 arithmetic: H/16 co-resident workgroups per weight set keep their
  * W_hh slice in registers for all T steps and exchange h_t through global memory (write-through stores, one arrive
@@ -229,7 +229,7 @@ void idv_lstm_pers_set_profile(unsigned long long* prof_cycles);
  *   [G0 16 TBH | G1 16 TBH | h0 4 TBH | h1 4 TBH | c0 4 TBH | c1 4 TBH | scratch]
  * G0: [z][T*B][8H] (z = real / imag input; columns [weight set s][4H]), G1: [run = 2z+s][T*B][4H], h/c: [run][T*B][H];
  * gate columns are ordered colp = ((u/16)*4 + gate)*16 + u%16. */
-long long idv_clstm_train_work_floats(int H, int B, int T, int Jp);   /* 48*T*B*H + 4*B*H + 4*H*Jp */
+long long idv_clstm_train_work_floats(int H, int B, int T, int Jp);   /* 48*T*B*H + 4*B*H + scratch(H, B, Jp) */
 /* wih1_bf16 (may be NULL): idv_pack_lstm_ih_bf16 of layer 1; with it, flags bit 0 and the persistent recurrence, layer 0
  * hands h0 to the layer-1 projection as a split image (idv_lstm_proj1_bf16x3) instead of fp32 rows. */
 int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0, const float* wih1,

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(amd):
     assert lib.idv_cconv_cck(ctypes.c_int(1)) == 2 and lib.idv_cconv_cck(ctypes.c_int(32)) == 4
     assert lib.idv_cconv_config(ctypes.c_int(1), ctypes.c_int(64), ctypes.c_int(1), ctypes.c_int(129)) == 1000001          # the one-output-channel vector-ALU kernel
     lib.idv_clstm_work_floats.restype = ctypes.c_longlong
-    assert lib.idv_clstm_work_floats(ctypes.c_int(128), ctypes.c_int(2), ctypes.c_int(641), ctypes.c_int(1284)) == 24 * 641 * 2 * 128 + 4 * 2 * 128 + 8 * 128 * 1284
+    assert lib.idv_clstm_work_floats(ctypes.c_int(128), ctypes.c_int(2), ctypes.c_int(641), ctypes.c_int(1284)) == 24 * 641 * 2 * 128 + 4 * 2 * 128 + 8 * 128 * 1284          # scratch = 4*H*Jp here (>= the cooperative exchange buffer)
 
 
 def test_missing_library_fails_loudly(amd, monkeypatch):
