@@ -27,6 +27,27 @@ def test_library_exports_every_declared_symbol(amd):
     assert lib.idv_clstm_work_floats(ctypes.c_int(128), ctypes.c_int(2), ctypes.c_int(641), ctypes.c_int(1284)) == 24 * 641 * 2 * 128 + 4 * 2 * 128 + 8 * 128 * 1284          # scratch = 4*H*Jp here (>= the cooperative exchange buffer)
 
 
+def test_lstm_scratch_covers_the_cooperative_exchange_buffers(amd):
+    """The scratch region inside idv_clstm_fwd's work buffer also hosts the exchange buffer + arrive counters of the
+    cooperative recurrences, whose size does not shrink with T or Jp (a short input used to overflow it)."""
+    lib = amd._lib.lib()
+    I, LL = ctypes.c_int, ctypes.c_longlong
+    for fn in (lib.idv_clstm_work_floats, lib.idv_clstm_train_work_floats, lib.idv_lstm_pers_work_bytes, lib.idv_lstm_coop_f32_work_bytes):
+        fn.restype = LL
+    for H, B, T, Jp in ((128, 1, 3, 8), (128, 64, 17, 64 * 18), (384, 3, 5, 20), (768, 32, 2, 96), (768, 20, 7, 160), (384, 64, 641, 64 * 642)):
+        need = 0
+        if lib.idv_lstm_pers_supported(I(H), I(B)):
+            need = max(need, lib.idv_lstm_pers_work_bytes(I(H), I(B)))
+        if lib.idv_lstm_coop_f32_supported(I(H), I(B)):
+            need = max(need, lib.idv_lstm_coop_f32_work_bytes(I(H), I(B)))
+        assert need > 0
+        TBH = T * B * H
+        scratch_eval = lib.idv_clstm_work_floats(I(H), I(B), I(T), I(Jp)) - (24 * TBH + 4 * B * H + 4 * H * Jp)
+        scratch_train = lib.idv_clstm_train_work_floats(I(H), I(B), I(T), I(Jp)) - (48 * TBH + 4 * B * H)
+        assert 4 * scratch_eval >= need and 4 * scratch_train >= need, (H, B, T, Jp, scratch_eval, scratch_train, need)
+        assert scratch_eval >= 4 * H * Jp and scratch_train >= 4 * H * Jp
+
+
 def test_missing_library_fails_loudly(amd, monkeypatch):
     L = amd._lib
     monkeypatch.setattr(L, "_lib", None)
