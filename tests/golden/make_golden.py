@@ -343,12 +343,12 @@ def summarize(t, limit=16384, cap=8192):
     return t[::stride].clone()
 
 
-def grad_record(out, prefix, module):
+def grad_record(out, prefix, module, limit=16384, cap=8192):
     """Per parameter: summarised gradient + its L2 norm (norm catches errors outside the subsample)."""
     for k, p_ in module.named_parameters():
         if p_.grad is None:
             continue
-        out[f"g:{prefix}{k}"] = summarize(p_.grad)
+        out[f"g:{prefix}{k}"] = summarize(p_.grad, limit, cap)
         out[f"n:{prefix}{k}"] = p_.grad.double().norm()
 
 
@@ -364,7 +364,7 @@ def adam_record(out, prefix, module, lr=1e-3, wd=1e-3):
             out[f"a:{prefix}{k}"] = summarize(p_)
 
 
-def gen_grad_dccrn(tag, base, B, L, seed, weights):
+def gen_grad_dccrn(tag, base, B, L, seed, weights, limit=16384, cap=8192, adam=True):
     print(f"== grads DCCRN_ {tag}: base={base} B={B} L={L} weights={weights}")
     np_ = O.net_params(True, base)
     skip = [0, 1, 2, 3, 4, 5]
@@ -379,10 +379,11 @@ def gen_grad_dccrn(tag, base, B, L, seed, weights):
         loss = R_nl.ete_train_se_loss(weights).final_ete_loss(pred, m.stft(clean_ref), clean_ref, est)
         loss[0].backward()
     out = dict(x=x.detach(), clean_ref=clean_ref, seed=seed, base=base, weights=np.asarray(weights, dtype="float32"),
-               loss=torch.stack([v.detach() for v in loss]), gx=x.grad, est=est.detach())
-    grad_record(out, "", m)
-    with torch.no_grad():
-        adam_record(out, "", m)
+               loss=torch.stack([v.detach() for v in loss]), gx=x.grad, est=est.detach(), sum_limit=limit, sum_cap=cap)
+    grad_record(out, "", m, limit, cap)
+    if adam:
+        with torch.no_grad():
+            adam_record(out, "", m)
     save(f"grad_dccrn_{tag}", **out)
 
 
@@ -627,6 +628,11 @@ if __name__ == "__main__":
     if "grads" in which:
         gen_grad_dccrn("mini", 4, 2, 1600, 61, [0.2, 0.1, 1.0])
         gen_grad_vae("mini", 4, 32, 2, 1600, 2, 71)
+    if "gradfull" in which:
+        # the supervised train step at the reference's FULL width (base 32), 1 s utterances: gradients subsampled to 1024
+        # elements per tensor + full L2 norms
+        torch.set_num_threads(os.cpu_count())
+        gen_grad_dccrn("full", 32, 2, 16000, 91, [0.2, 0.1, 1.0], limit=2048, cap=1024, adam=False)
     if "extras" in which:
         gen_datanorm()
         gen_checkpoint()

@@ -343,10 +343,12 @@ def summarize(t, limit=16384, cap=8192):
     return t[::-(-t.numel() // cap)]
 
 
-def check_grads(d, prefix, module, tol=1e-3):
-    """Every parameter gradient of `module` against the reference's (summarised gradient + full L2 norm)."""
+def check_grads(d, prefix, module, tol=1e-3, tol1=None):
+    """Every parameter gradient of `module` against the reference's (summarised gradient + full L2 norm); tol1: tolerance
+    for one-element tensors (default tol)."""
     n = 0
     worst = (0.0, "")
+    lim = (int(d["sum_limit"]), int(d["sum_cap"])) if "sum_limit" in d.files else (16384, 8192)
     for k, p_ in module.named_parameters():
         key = f"g:{prefix}{k}"
         if key not in d.files:
@@ -354,8 +356,9 @@ def check_grads(d, prefix, module, tol=1e-3):
             continue
         assert p_.grad is not None, f"{k}: no gradient"
         want, wn = T_(d[key]).double(), float(d[f"n:{prefix}{k}"])
-        got = summarize(p_.grad).cpu().double()
+        got = summarize(p_.grad, *lim).cpu().double()
         scale = max(wn * (want.numel() / p_.numel()) ** 0.5, 1e-12)
+        tk = tol1 if (tol1 is not None and p_.numel() == 1) else tol
         err = float((got - want).norm()) / scale
         gn = float(p_.grad.double().norm())
         sib = f"n:{prefix}{k[:-4]}weight"
@@ -364,9 +367,10 @@ def check_grads(d, prefix, module, tol=1e-3):
             # compare against the scale of the layer's weight gradient instead
             assert gn < 1e-3 * float(d[sib]), (k, gn, wn, float(d[sib]))
         else:
-            assert err < tol, f"{k}: rel err {err:.2e}"
-            assert abs(gn - wn) < tol * wn, f"{k}: norm {gn} vs {wn}"
-            worst = max(worst, (err, k))
+            assert err < tk, f"{k}: rel err {err:.2e}"
+            assert abs(gn - wn) < tk * wn, f"{k}: norm {gn} vs {wn}"
+            if p_.numel() > 1 or tol1 is None:
+                worst = max(worst, (err, k))
         n += 1
     assert n > 0
     return worst
@@ -415,6 +419,41 @@ def test_grad_dccrn_reference(pm, losses, golden):
     worst = check_grads(d, "", m)
     print("worst parameter-gradient error", worst)
     check_adam(d, "", m)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_grad_dccrn_reference_full_width(pm, losses, golden, ops, precision):
+    """The same train step at the reference's FULL width (base 32: every kernel at the benchmark's tile counts) on 1 s
+    utterances against gradients written by the REAL reference (make_golden.py gradfull: 1024-element subsample + full L2
+    norm per tensor), in both arithmetic modes.  Tolerance 1e-2 (3e-2 for one-element tensors) for the reason given in
+    test_full_width_train_step_grads: a handful of PReLU pre-activations within rounding of zero take the other branch
+    (measured worst multi-element tensor: 4.4e-3).  bf16x3: the forward rounding is 1e-5 instead of 1e-6, ten times as many
+    pre-activations lie within it, the deviation grows with the square root: 3e-2 (measured 8.8e-3)."""
+    d = golden("grad_dccrn_full")
+    nl, _, _ = losses
+    base, seed = int(d["base"]), int(d["seed"])
+    np_ = O.net_params(True, base)
+    keep = ops.PRECISION
+    ops.set_precision(precision)
+    try:
+        m = load_synth(pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None), seed)
+        m.train()
+        x = T_(d["x"]).cuda().requires_grad_(True)
+        clean_ref = T_(d["clean_ref"]).cuda()
+        w = [float(v) for v in d["weights"]]
+        with torch.enable_grad():
+            est, pred = m(x, train=True)
+            loss = nl.ete_train_se_loss(w).final_ete_loss(pred, m.stft(clean_ref), clean_ref, est)
+            loss[0].backward()
+    finally:
+        ops.set_precision(keep)
+    assert relerr(est.detach().cpu(), T_(d["est"])) < 1e-4
+    for a, b in zip(loss, T_(d["loss"])):
+        assert abs(float(a) - float(b)) < 2e-4 * max(1.0, abs(float(b)))
+    tol = 1e-2 if precision == "fp32" else 3e-2
+    assert relerr(x.grad.cpu(), T_(d["gx"])) < tol
+    worst = check_grads(d, "", m, tol=tol, tol1=3 * tol)
+    print("worst parameter-gradient error vs the reference", worst)
 
 
 def test_grad_cvae_reference(pm, losses, golden):
