@@ -163,11 +163,15 @@ def _summ(t, limit=16384, cap=8192):
     return t if t.numel() <= limit else t[::-(-t.numel() // cap)]
 
 
-def test_oracle_backward_is_pinned_by_reference_gradients(golden):
+@pytest.mark.parametrize("fixture,tol", [("grad_dccrn_mini", 2e-3), ("grad_dccrn_full", 1e-2)])
+def test_oracle_backward_is_pinned_by_reference_gradients(golden, fixture, tol):
     """torch.autograd through the oracle's DCCRN forward + loss reproduces the REAL reference's parameter and input
-    gradients (tests/golden/grad_dccrn_mini.npz, written by make_golden.py `grads`): the GPU gradient tests that compare
-    against oracle autograd therefore compare against the reference."""
-    d = golden("grad_dccrn_mini")
+    gradients (tests/golden/grad_dccrn_mini.npz / grad_dccrn_full.npz, written by make_golden.py `grads` / `gradfull`): the
+    GPU gradient tests that compare against oracle autograd therefore compare against the reference.  Full width (base 32):
+    1e-2 (3e-2 for one-element tensors) -- two fp32 evaluations in different summation orders disagree on the PReLU branch
+    of a handful of near-zero pre-activations (tests/test_gpu_backward.py::test_full_width_train_step_grads)."""
+    d = golden(fixture)
+    lim = (int(d["sum_limit"]), int(d["sum_cap"])) if "sum_limit" in d.files else (16384, 8192)
     base, seed = int(d["base"]), int(d["seed"])
     np_ = O.net_params(True, base)
     shapes = {}
@@ -187,7 +191,7 @@ def test_oracle_backward_is_pinned_by_reference_gradients(golden):
     loss = O.multiple_recon_loss(pred, O.stft(clean_ref, NFFT, HOP, WIN), clean_ref, est, w)
     loss[0].backward()
     assert relerr(est.detach(), torch.from_numpy(d["est"])) < 1e-4
-    assert relerr(x.grad, torch.from_numpy(d["gx"])) < 1e-3
+    assert relerr(x.grad, torch.from_numpy(d["gx"])) < max(1e-3, tol)
     checked = 0
     for k in d.files:
         if not k.startswith("g:"):
@@ -199,8 +203,8 @@ def test_oracle_backward_is_pinned_by_reference_gradients(golden):
         sib = "n:" + name[:-4] + "weight"
         if name.endswith(".bias") and sib in d.files and wn < 1e-4 * float(d[sib]):
             continue                                 # true-zero gradients (bias in front of a batch norm): rounding noise
-        got = _summ(g).double()
+        got = _summ(g, *lim).double()
         scale = max(wn * (want.numel() / g.numel()) ** 0.5, 1e-12)
-        assert float((got - want).norm()) / scale < 2e-3, name
+        assert float((got - want).norm()) / scale < (3 * tol if g.numel() == 1 else tol), name
         checked += 1
     assert checked > 100
