@@ -31,6 +31,7 @@ struct CoopArgs {
     unsigned* sync;           // [abort flag: 256 B][group = run * tiles + tile][replica][256 B]
     int nrep;
     int B, T, Bpad, tiles;
+    int fault;                // test hook (IDV_COOP_FAULT=1): workgroup (0, 0, 0) never arrives -> the bounded spins must abort
 };
 
 constexpr int H = 128, NSL = 4, UPW = 32;          // hidden size, workgroups per group, units per workgroup
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_f32_kernel(const CoopArgs a)
 
     bool aborted = false;
     if (tid == 0) abort_sh = 0;
+    if (a.fault && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) return;      // injected failure (tests only)
     for (int t = 0; t < a.T; ++t) {
         float gpre[2][4];
         {
@@ -220,6 +222,7 @@ extern "C" int idv_lstm_rec_coop_f32(const float* g, long long g_run_z, long lon
     a.hx_bytes = (unsigned)(2LL * 4 * Bpad * H * 4);
     a.nrep = 4;
     a.B = B; a.T = T; a.Bpad = (int)Bpad; a.tiles = tiles;
+    { const char* e = getenv("IDV_COOP_FAULT"); a.fault = (e && e[0] == '1') ? 1 : 0; }
     const size_t smem = 84 * 1024;                   // > half a CU's LDS: one workgroup per CU (red[] needs 32 KB)
     if (hipFuncSetAttribute((const void*)lstm_coop_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return IDV_ELAUNCH;

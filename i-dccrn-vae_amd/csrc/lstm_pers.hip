@@ -42,6 +42,7 @@ struct PersArgs {
     unsigned* sync;           // [abort flag: 256 B][group = set * chunks + chunk][replica][256 B] arrive counters
     int nrep;                 // replicas of each arrive counter (1, 2, 4 or 8), each on a 256-byte block of its own
     int H, B, T, Bpad, nchunks;
+    int fault;                // test hook (IDV_COOP_FAULT=1): workgroup (0, 0, 0) never arrives -> the bounded spins must abort
     unsigned long long* prof; // diagnostic build only: [workgroup][8] accumulated phase cycles, [7] = XCC id
 };
 
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
 
     bool aborted = false;
     if (tid == 0) abort_sh = 0;
+    if (a.fault && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) return;      // injected failure (tests only)
     const bool pw = PROF && wave == 0;
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = 0;
     if (PROF && pw) plast = __builtin_readcyclecounter();
@@ -399,6 +401,7 @@ extern "C" int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_
     a.hx_bytes = (unsigned)hx_bytes;
     a.nrep = nrep;
     a.H = H; a.B = B; a.T = T; a.Bpad = (int)Bpad; a.nchunks = chunks; a.prof = prof;
+    { const char* e = getenv("IDV_COOP_FAULT"); a.fault = (e && e[0] == '1') ? 1 : 0; }
     dim3 grid(H / 16, 2, chunks);
     // at least 84 KB of LDS per workgroup: ONE workgroup per CU whatever the register count (the hand-off form above is the
     // one measured for one workgroup per CU, and co-located workgroups would share one CU's miss bandwidth)

@@ -334,6 +334,47 @@ def test_clstm_coop_f32_matches_one_cu(ops, B, T):
     assert relerr(got.cpu(), ref.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("H,precision", [(128, "fp32"), (384, "bf16x3")])
+def test_cooperative_recurrence_times_out_instead_of_hanging(ops, H, precision):
+    """Safety net of the cooperative recurrences (lstm_coop_f32.hip, lstm_pers.hip): with one workgroup withheld
+    (IDV_COOP_FAULT=1 makes workgroup (0, 0, 0) return before its first arrive) every spin runs into its bound, the abort
+    flag drains the grid, the outputs are poisoned with NaN -- the call returns within a second, nothing hangs, nothing
+    looks like a result -- and the next call without the fault is correct again."""
+    import os
+    import time
+    B, T, I = 5, 12, 64
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(T, B, I, 2, generator=g) * 0.5
+    names = [f"lstm_{s}.{w}_l{l}" for s in ("re", "im") for l in (0, 1) for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    sd = {}
+    for n in names:
+        l = int(n[-1])
+        shape = (4 * H, I if l == 0 else H) if "weight_ih" in n else ((4 * H, H) if "weight_hh" in n else (4 * H,))
+        sd[n] = O.synth_tensor(n, shape, 94)
+    xp = ops.Planar.from_tensor5(x.permute(1, 2, 0, 3).unsqueeze(2).cuda())
+    get = lambda n: sd[n].cuda()
+    keep = ops.PRECISION
+    try:
+        ops.set_precision(precision)
+        p0, p1 = ops.pack_lstm(get, H, I, 0, "cuda"), ops.pack_lstm(get, H, H, 1, "cuda")
+        good = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
+        torch.cuda.synchronize()
+        os.environ["IDV_COOP_FAULT"] = "1"
+        t0 = time.perf_counter()
+        bad = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        os.environ.pop("IDV_COOP_FAULT")
+        again = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("IDV_COOP_FAULT", None)
+        ops.set_precision(keep)
+    assert dt < 5.0, dt                                   # two layers x one 0.4 s spin bound
+    assert torch.isnan(bad).any()
+    assert torch.isfinite(good).all() and torch.equal(good, again)
+
+
 def amd_lib():
     import importlib
     return importlib.import_module("i-dccrn-vae_amd")._lib.lib()
