@@ -297,12 +297,20 @@ extern "C" int idv_rows_to_planar(const float* src, long long ld, int c0, int nc
 
 extern "C" long long idv_lstm_bptt_work_floats(int H, int B) {
     const long long ntb = (B + 15) / 16;
-    return 4LL * B * H + 2LL * 4 * ntb * 4 * H * 16;
+    long long n = 4LL * B * H + 2LL * 4 * ntb * 4 * H * 16;
+    if (idv_lstm_bptt_coop_supported(H, B)) {                   // the cooperative form's exchange buffer + counters
+        const long long m = (idv_lstm_bptt_coop_work_bytes(H, B) + 3) / 4;
+        if (m > n) n = m;
+    }
+    return n;
 }
 
 extern "C" int idv_lstm_bptt(float* gates, long long g_run_z, long long g_run_s, int ldg, const float* cstates,
                              const float* dhout, const float* whhT, int H, int B, int T, float* work, void* stream) {
     if (!gates || !cstates || !dhout || !whhT || !work || H <= 0 || (H % 16) || B <= 0 || T <= 0 || ldg < 4 * H) return IDV_EINVAL;
+    // H = 128: one cooperative launch per layer (lstm_bptt_coop_f32.hip) instead of one launch per step
+    if (idv_lstm_bptt_coop_supported(H, B) && !(reinterpret_cast<uintptr_t>(work) & 15))
+        return idv_lstm_bptt_coop(gates, g_run_z, g_run_s, ldg, cstates, dhout, whhT, H, B, T, (void*)work, stream);
     BpttArgs a{};
     a.g = gates; a.g_run_z = g_run_z; a.g_run_s = g_run_s; a.ldg = ldg;
     a.c = cstates; a.dhout = dhout; a.whhT = whhT;

@@ -408,6 +408,13 @@ int idv_pack_lstm_hh_bwd(const float* w_hh_re, const float* w_hh_im, int H, floa
 long long idv_lstm_bptt_work_floats(int H, int B);
 int idv_lstm_bptt(float* gates, long long g_run_z, long long g_run_s, int ldg, const float* cstates, const float* dhout,
                   const float* whhT, int H, int B, int T, float* work, void* stream);
+/* the same as ONE cooperative launch per layer for H = 128 (four workgroups per (run, 16-sequence tile), W_hh^T and the running
+ * dc in registers, dA_t exchanged with the fence-free hand-off of idv_lstm_rec_pers); idv_lstm_bptt dispatches to it when
+ * idv_lstm_bptt_coop_supported (IDV_LSTM_BPTT_COOP=0 keeps the per-step launches).  work: idv_lstm_bptt_coop_work_bytes. */
+int idv_lstm_bptt_coop_supported(int H, int B);
+long long idv_lstm_bptt_coop_work_bytes(int H, int B);
+int idv_lstm_bptt_coop(float* gates, long long g_run_z, long long g_run_s, int ldg, const float* cstates, const float* dhout,
+                       const float* whhT, int H, int B, int T, void* work, void* stream);
 int idv_rows_to_planar(const float* src, long long ld, int c0, int ncol, int B, int T, int Tp, int Jp, float* dst, void* stream);
 int idv_lstm_bias_grad(const float* dGp, int H, int Jp, int J, int accumulate, float* db, void* stream);
 
