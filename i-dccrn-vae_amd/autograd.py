@@ -79,7 +79,11 @@ class ConvBlockFn(torch.autograd.Function):
             bn._stats_gen += 1
             if first and not bn.dis_cbn:
                 bn.init_flag = False
-            z = ops.cbn_apply_to(y, fold, slope)
+            if ops.train_image_ok(cout) and y.Jp == x.Jp:
+                z, zimg = ops.cbn_apply_to(y, fold, slope, want_image=True)      # the next block reads the image
+                z.buf._idv_img = zimg
+            else:
+                z = ops.cbn_apply_to(y, fold, slope)
             ctx.save_for_backward(xbuf, skipbuf, w_re, w_im, y.buf, fold, moments, g_rr, g_ri, g_ii, slope)
         else:
             z = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, wfrag_bf16=wbf)
@@ -101,11 +105,16 @@ class ConvBlockFn(torch.autograd.Function):
         grads_bn = (None,) * 6
         if bn is not None:
             y = _mk(ybuf, ctx.zgeom)
+            want_img = _dy_image_wanted(cout) and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
             dy, dgrr, dgri, dgii, dbr, dbi, dslope = ops.cbn_bwd(dz, y, fold, moments, (g_rr, g_ri, g_ii), slope,
-                                                                 float(y.B) * y.F * y.T)
+                                                                 float(y.B) * y.F * y.T, want_image=want_img)
+            if want_img:
+                dy, dy_img_bn = dy
             grads_bn = (dgrr, dgri, dgii, dbr, dbi, dslope.reshape(slope.shape) if slope is not None else None)
         else:
             dy = dz
+        if bn is None or not want_img:
+            dy_img_bn = None
         # bias and weight gradients.  A conv bias in front of a batch norm has an exactly zero gradient: the backward of the
         # normalisation makes every channel of dy sum to zero over the batch (sum dy = Z^T sum du + A sum (y - mu) + N c with
         # sum (y - mu) = 0 and c = -Z^T sum du / N, cbn_bwd_finalize); what autograd returns there in the reference is
@@ -129,10 +138,10 @@ class ConvBlockFn(torch.autograd.Function):
             if not tr:      # conv [Cout][Cin]: adjoint = transposed conv, Cin' = Cout, Cout' = Cin (single source)
                 if skip is not None:
                     raise NotImplementedError("conv blocks take one source")
-                dx = _dgrad(dy, w_re, w_im, cin_total, cout, False, _dy_image(dy, cout))
+                dx = _dgrad(dy, w_re, w_im, cin_total, cout, False, dy_img_bn if dy_img_bn is not None else _dy_image(dy, cout))
             else:           # transposed conv [Cin][Cout]: adjoint = conv, Cout' = a slice of Cin, Cin' = Cout
                 per = cout * 10
-                dy_img = _dy_image(dy, cout)
+                dy_img = dy_img_bn if dy_img_bn is not None else _dy_image(dy, cout)
                 if need_x:
                     dx = _dgrad(dy, w_re, w_im, x.C, cout, True, dy_img)
                 if need_s:
@@ -167,11 +176,13 @@ def _image_of(buf: torch.Tensor, pl: Planar):
     return img
 
 
+def _dy_image_wanted(cin_adj: int) -> bool:
+    return ops.PRECISION == "bf16x3" and ops.IMAGE_TRAIN and cin_adj % 8 == 0 and 2 * cin_adj >= 64
+
+
 def _dy_image(dy: Planar, cin_adj: int):
     """Split image of dy for the data-gradient kernels of a block (None outside bf16x3 mode / unsupported channel counts)."""
-    if ops.PRECISION == "bf16x3" and ops.IMAGE_TRAIN and cin_adj % 8 == 0 and 2 * cin_adj >= 64:
-        return ops.to_image(dy)
-    return None
+    return ops.to_image(dy) if _dy_image_wanted(cin_adj) else None
 
 
 def conv_block(conv, bn, prelu_weight, x: Planar, skip: Optional[Planar], zero_skip: bool) -> Planar:

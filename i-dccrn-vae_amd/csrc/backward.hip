@@ -184,6 +184,114 @@ __global__ void cbn_apply_prelu_to_kernel(const float* __restrict__ y, const flo
     }
 }
 
+// ---- the same two element-wise passes writing, besides the planar result, its split-bf16 IMAGE (what the bf16x3 training
+// mode's conv kernels read): one workgroup row = (octet of 4 channels, frequency row), a thread owns a column and the 8
+// planes of its slot, so every store is whole 16-byte slots (the separate planar -> image pass re-read the result: 1 of the
+// 11 activation-sized memory passes of a training block).  Needs C % 4 == 0.
+__device__ __forceinline__ void img_slot_store(unsigned short* __restrict__ img, long long lo_off, size_t slot, const float (&v)[8]) {
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float x0 = v[2 * w], x1 = v[2 * w + 1];
+        const unsigned u0 = __builtin_bit_cast(unsigned, x0) & 0xffff0000u, u1 = __builtin_bit_cast(unsigned, x1) & 0xffff0000u;
+        hw[w] = (u0 >> 16) | u1;
+        const float r0 = x0 - __builtin_bit_cast(float, u0), r1 = x1 - __builtin_bit_cast(float, u1);
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        const bf2 pk = {(__bf16)r0, (__bf16)r1};
+        lw[w] = __builtin_bit_cast(unsigned, pk);
+    }
+    *(uint4*)(img + slot * 8) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+    *(uint4*)(img + lo_off + slot * 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+}
+
+__device__ __forceinline__ void img_edge_zero(unsigned short* __restrict__ img, long long lo_off, long long nslots) {
+    // the zero slot in front of each plane (rows outside [0, F)) and 8 zero slots behind it (tshift-0 consumers), as
+    // planar_to_image_kernel (image.hip)
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        const int t = threadIdx.x;
+        if (t < 2) *(uint4*)(img - 8 * 8 + (t ? lo_off : 0)) = make_uint4(0u, 0u, 0u, 0u);
+        if (t >= 32 && t < 48) *(uint4*)(img + (nslots + (t & 7)) * 8 + ((t & 8) ? lo_off : 0)) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+__global__ void cbn_apply_prelu_to_img_kernel(const float* __restrict__ y, const float* __restrict__ fold,
+                                              const float* __restrict__ slope_p, int C, int F, int B, int Tp, int Jp, int t_valid,
+                                              float* __restrict__ out, unsigned short* __restrict__ img, long long lo_off) {
+    const int o = blockIdx.y / F, f = blockIdx.y - o * F;
+    const float slope = slope_p ? *slope_p : 1.0f;
+    const int J = B * Tp;
+    img_edge_zero(img, lo_off, (long long)(C / 4) * F * Jp);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < Jp; j += gridDim.x * blockDim.x) {
+        const int tp = j % Tp;
+        const bool keep = j < J && tp >= 1 && tp <= t_valid;
+        float v[8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = 4 * o + w;
+            const float* z = fold + (size_t)c * 6;
+            const size_t ro = ((size_t)c * F + f) * Jp + j, io = ((size_t)(C + c) * F + f) * Jp + j;
+            float yr = 0.f, yi = 0.f;
+            if (keep) {
+                const float r = y[ro], im = y[io];
+                yr = z[0] * r + z[1] * im + z[4];
+                yi = z[2] * r + z[3] * im + z[5];
+                yr = yr >= 0.f ? yr : slope * yr;
+                yi = yi >= 0.f ? yi : slope * yi;
+            }
+            if (j < J) {
+                out[ro] = yr;
+                out[io] = yi;
+            }
+            v[2 * w] = yr;
+            v[2 * w + 1] = yi;
+        }
+        img_slot_store(img, lo_off, ((size_t)o * F + f) * Jp + j, v);
+    }
+}
+
+__global__ void cbn_bwd_apply_img_kernel(const float* __restrict__ dz, const float* __restrict__ y, const float* __restrict__ fold,
+                                         const float* __restrict__ coef, const float* __restrict__ slope_p, int C, int F, int B,
+                                         int Tp, int Jp, int t_valid, float* __restrict__ dy, unsigned short* __restrict__ img,
+                                         long long lo_off) {
+    const int o = blockIdx.y / F, f = blockIdx.y - o * F;
+    const bool act = slope_p != nullptr;
+    const float slope = act ? *slope_p : 1.0f;
+    const int J = B * Tp;
+    img_edge_zero(img, lo_off, (long long)(C / 4) * F * Jp);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < Jp; j += gridDim.x * blockDim.x) {
+        const int tp = j % Tp;
+        const bool keep = j < J && tp >= 1 && tp <= t_valid;
+        float v[8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = 4 * o + w;
+            const float* z = fold + (size_t)c * 6;
+            const float* k = coef + (size_t)c * 12;
+            const size_t ro = ((size_t)c * F + f) * Jp + j, io = ((size_t)(C + c) * F + f) * Jp + j;
+            float or_ = 0.f, oi = 0.f;
+            if (keep) {
+                const float yr = y[ro], yi = y[io];
+                float dr = dz[ro], di = dz[io];
+                if (act) {
+                    const float ur = z[0] * yr + z[1] * yi + z[4], ui = z[2] * yr + z[3] * yi + z[5];
+                    if (!(ur > 0.f)) dr *= slope;
+                    if (!(ui > 0.f)) di *= slope;
+                }
+                const float cyr = yr - k[9], cyi = yi - k[10];
+                or_ = k[0] * dr + k[2] * di + k[4] * cyr + k[5] * cyi + k[7];
+                oi = k[1] * dr + k[3] * di + k[6] * cyi + k[5] * cyr + k[8];
+            }
+            if (j < J) {
+                dy[ro] = or_;
+                dy[io] = oi;
+            }
+            v[2 * w] = or_;
+            v[2 * w + 1] = oi;
+        }
+        img_slot_store(img, lo_off, ((size_t)o * F + f) * Jp + j, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // mask branch (pvae_module.py:224-234): P = tanh|M| * X * M/|M|.  With G = dL/dP, u = M/|M|, q = X u, g = tanh|M|:
 //   dL/dM = (g' - g/|M|) (G . q) u + (g/|M|) conj(X) G          (g' = 1 - g^2)
@@ -532,6 +640,33 @@ extern "C" int idv_cbn_apply_prelu_to(const float* y, const float* fold, const f
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(cbn_apply_prelu_to_kernel, dim3(gx, C * F), dim3(256), 0, (hipStream_t)stream, y, fold, prelu_slope, C,
                        F, B, Tp, Jp, t_valid, out);
+    return idv_launch_status();
+}
+
+// idv_cbn_apply_prelu_to writing the split image of the result as well (img: hi plane, lo plane lo_off_elems bf16 further;
+// C % 4 == 0; layout and edge slots as idv_planar_to_image)
+extern "C" int idv_cbn_apply_prelu_to_img(const float* y, const float* fold, const float* prelu_slope, int C, int F, int B, int Tp,
+                                          int Jp, int t_valid, float* out, void* img, long long lo_off_elems, void* stream) {
+    if (!y || !fold || !out || !img || C <= 0 || (C % 4) || F <= 0 || B <= 0 || Jp < B * Tp || (lo_off_elems % 8) ||
+        (reinterpret_cast<uintptr_t>(img) & 15))
+        return IDV_EINVAL;
+    int gx = (Jp + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(cbn_apply_prelu_to_img_kernel, dim3(gx, (C / 4) * F), dim3(256), 0, (hipStream_t)stream, y, fold, prelu_slope,
+                       C, F, B, Tp, Jp, t_valid, out, (unsigned short*)img, lo_off_elems);
+    return idv_launch_status();
+}
+
+extern "C" int idv_cbn_bwd_apply_img(const float* dz, const float* y, const float* fold, const float* coef, const float* prelu_slope,
+                                     int C, int F, int B, int Tp, int Jp, int t_valid, float* dy, void* img, long long lo_off_elems,
+                                     void* stream) {
+    if (!dz || !y || !fold || !coef || !dy || !img || C <= 0 || (C % 4) || F <= 0 || B <= 0 || Jp < B * Tp || (lo_off_elems % 8) ||
+        (reinterpret_cast<uintptr_t>(img) & 15))
+        return IDV_EINVAL;
+    int gx = (Jp + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(cbn_bwd_apply_img_kernel, dim3(gx, (C / 4) * F), dim3(256), 0, (hipStream_t)stream, dz, y, fold, coef,
+                       prelu_slope, C, F, B, Tp, Jp, t_valid, dy, (unsigned short*)img, lo_off_elems);
     return idv_launch_status();
 }
 

@@ -830,8 +830,19 @@ def cconv_bias_grad(dy: Planar):
     return db_re, db_im
 
 
-def cbn_apply_to(y: Planar, fold, slope) -> Planar:
+def train_image_ok(C: int) -> bool:
+    """bf16x3 training: is an activation with C channels worth a split image (the image conv kernels take it as a source)?"""
+    return PRECISION == "bf16x3" and IMAGE_TRAIN and C % 8 == 0 and 2 * C >= 64
+
+
+def cbn_apply_to(y: Planar, fold, slope, want_image: bool = False):
+    """-> z (Planar), or (z, Image of z) with want_image (one pass writes both)."""
     out = like(y)
+    if want_image:
+        img = Image.empty(y.C, y.F, y.B, y.T, y.Tp, y.buf.device)
+        call("idv_cbn_apply_prelu_to_img", y.ptr(), p(fold), p(slope), i(y.C), i(y.F), i(y.B), i(y.Tp), i(y.Jp), i(y.T), out.ptr(),
+             img.ptr(), ll(img.lo_off), stream_ptr())
+        return out, img
     call("idv_cbn_apply_prelu_to", y.ptr(), p(fold), p(slope), i(y.C), i(y.F), i(y.B), i(y.Tp), i(y.Jp), i(y.T), out.ptr(),
          stream_ptr())
     return out
@@ -843,8 +854,8 @@ def cbn_apply_to(y: Planar, fold, slope) -> Planar:
 BN_SYNC = None
 
 
-def cbn_bwd(dz: Planar, y: Planar, fold, moments, bn, slope, count: float):
-    """-> (dy, d gamma_rr, d gamma_ri, d gamma_ii, d beta_r, d beta_i, dslope[1])"""
+def cbn_bwd(dz: Planar, y: Planar, fold, moments, bn, slope, count: float, want_image: bool = False):
+    """-> (dy, d gamma_rr, d gamma_ri, d gamma_ii, d beta_r, d beta_i, dslope[1]); want_image: dy is (Planar, Image)."""
     C, dev = y.C, y.buf.device
     sums = torch.empty(C, 8, dtype=torch.float64, device=dev)
     call("idv_cbn_bwd_reduce", dz.ptr(), y.ptr(), p(fold), p(slope), i(C), i(y.F), i(y.B), i(y.Tp), i(y.Jp), i(y.T), p(sums),
@@ -859,6 +870,11 @@ def cbn_bwd(dz: Planar, y: Planar, fold, moments, bn, slope, count: float):
     call("idv_cbn_bwd_finalize", p(sums), d(count), p(moments), p(bn[0]), p(bn[1]), p(bn[2]), i(C), p(coef), p(g[0]), p(g[1]),
          p(g[2]), p(g[3]), p(g[4]), p(dslope if slope is not None else None), f(1.0 / world), stream_ptr())
     dy = like(y)
+    if want_image:
+        img = Image.empty(y.C, y.F, y.B, y.T, y.Tp, dev)
+        call("idv_cbn_bwd_apply_img", dz.ptr(), y.ptr(), p(fold), p(coef), p(slope), i(C), i(y.F), i(y.B), i(y.Tp), i(y.Jp), i(y.T),
+             dy.ptr(), img.ptr(), ll(img.lo_off), stream_ptr())
+        return ((dy, img), *g, dslope)
     call("idv_cbn_bwd_apply", dz.ptr(), y.ptr(), p(fold), p(coef), p(slope), i(C), i(y.F), i(y.B), i(y.Tp), i(y.Jp), i(y.T),
          dy.ptr(), stream_ptr())
     return (dy, *g, dslope)

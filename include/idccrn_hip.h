@@ -357,6 +357,12 @@ int idv_cbn_bwd_finalize(const double* sums, double count, const float* moments,
                          float* dbeta_r, float* dbeta_i, float* dslope, float param_grad_scale, void* stream);
 int idv_cbn_bwd_apply(const float* dz, const float* y, const float* fold, const float* coef, const float* prelu_slope, int C,
                       int F, int B, int Tp, int Jp, int t_valid, float* dy, void* stream);
+/* the out-of-place normalise + PReLU and the batch-norm backward apply, each also writing the split image of its result (bf16x3
+ * training mode: the conv kernels read images; C % 4 == 0; image layout and edge slots as idv_planar_to_image) */
+int idv_cbn_apply_prelu_to_img(const float* y, const float* fold, const float* prelu_slope, int C, int F, int B, int Tp, int Jp,
+                               int t_valid, float* out, void* img, long long lo_off_elems, void* stream);
+int idv_cbn_bwd_apply_img(const float* dz, const float* y, const float* fold, const float* coef, const float* prelu_slope, int C,
+                          int F, int B, int Tp, int Jp, int t_valid, float* dy, void* img, long long lo_off_elems, void* stream);
 
 /* idv_mask_apply backward (pvae_module.py:224-234): gradient w.r.t. the mask from the gradients of the planar prediction
  * and / or of the interleaved complex64 tensor (either may be NULL); dX (optional, x_div == 1 only): gradient w.r.t. the
