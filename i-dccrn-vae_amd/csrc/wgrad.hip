@@ -390,6 +390,12 @@ void launch_wgrad_unpack_conv(const float* part, int nsplit, int SpPad, int LpPa
                        LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
 }
 
+void launch_wgrad_unpack_plain(const float* part, int nsplit, int SpPad, int LpPad, int M, int K, int ldw, int rowmap, int H,
+                               int accumulate, float* dw, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_unpack_plain_kernel, dim3(grid_for((long long)M * K)), dim3(256), 0, st, part, nsplit, SpPad, LpPad, M,
+                       K, ldw, rowmap, H, accumulate, dw);
+}
+
 extern "C" long long idv_cconv_wgrad_work_floats(int Cs, int Cl, int B, int Tp) {
     if (Cs <= 0 || Cl <= 0 || B <= 0 || Tp <= 0) return -1;
     if (2 * Cl <= SK_LP) {

@@ -216,6 +216,131 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a) {
             }
 }
 
+// ---- point-wise form (LSTM input / recurrent projections, ComplexDense, DFT matrices): G[s][l] = sum_j S[s][j] L[l][j + shift]
+// The weight gradients of the H = 384 / 768 LSTM projections were 16 % of the NSVAE train step on the fp32 kernel.
+// 128 x 128 plane tile, 2 x 2 waves of 64 x 64 (four 32 x 32 accumulator tiles), 32 columns per step, both operands split
+// on the fly as above; shift = -1 (h_{t-1} is one column to the left; the guard column supplies h_{-1} = 0) is a column
+// offset of the L loads.
+constexpr int PW_MS = 128, PW_ML = 128, PWJ = 32;
+
+__global__ __launch_bounds__(256, 2) void wgrad_pw_bf16_kernel(const WgradArgs a) {
+    constexpr int Q4 = PWJ / 4;
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) unsigned short Ssm[2][PW_MS][BW_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Lsm[2][PW_ML][BW_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int split = blockIdx.x, ts = blockIdx.y, tl = blockIdx.z;
+    const int sp0 = ts * PW_MS, lp0 = tl * PW_ML;
+    const int jt0 = split * a.jt_per_split;
+    int jt1 = jt0 + a.jt_per_split;
+    if (jt1 > a.jtiles) jt1 = a.jtiles;
+    const int nsteps = jt1 > jt0 ? jt1 - jt0 : 0;
+    const __amdgpu_buffer_rsrc_t Sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.S, 0, (unsigned)((size_t)a.Sp * a.JpS * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t Lr = __builtin_amdgcn_make_buffer_rsrc((void*)a.L, 0, (unsigned)((size_t)a.Lp * a.JpL * 4), 0x00020000);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+
+    const int q = tid & (Q4 - 1), r8 = tid / Q4;
+    const unsigned sbase = (unsigned)(((size_t)(sp0 + r8) * a.JpS + 4 * q) * 4), sstep = (unsigned)((size_t)32 * a.JpS * 4);
+    const unsigned lbase = (unsigned)(((size_t)(lp0 + r8) * a.JpL + 4 * q) * 4), lstep = (unsigned)((size_t)32 * a.JpL * 4);
+    f32x4 sreg[4], lreg[4];
+
+    auto load_step = [&](int step) {
+        const int j0 = (jt0 + step) * PWJ;
+        const int js = j0 + 4 * q;                   // first S column of the slot
+        int jl = js + a.dt0;                         // first L column (dt0 = shift: 0 or -1)
+        const bool neg = jl < 0;                     // only column -1 of the first slot: load columns 0 .. 3, rotate at the store
+        if (neg) jl = 0;
+        const unsigned us = (unsigned)((long long)j0 * 4), ul = (unsigned)(((long long)j0 + (neg ? 0 : a.dt0)) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                Sr, (js < a.J && sp0 + r8 + 32 * i < a.Sp) ? sbase + i * sstep + us : OOB, 0, 0));
+            lreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                Lr, (jl < a.J && lp0 + r8 + 32 * i < a.Lp) ? lbase + i * lstep + ul : OOB, 0, 0));
+        }
+    };
+    auto store_step = [&](int step) {
+        const int j0 = (jt0 + step) * PWJ;
+        const int js = j0 + 4 * q, jl = js + a.dt0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s0 = sreg[i][0], s1 = sreg[i][1], s2 = sreg[i][2], s3 = sreg[i][3];
+            float l0 = lreg[i][0], l1 = lreg[i][1], l2 = lreg[i][2], l3 = lreg[i][3];
+            if (jl < 0) { l3 = l2; l2 = l1; l1 = l0; l0 = 0.f; }          // the slot loaded columns 0 .. 3; it holds -1 .. 2
+            if (j0 + PWJ > a.J) {                                         // last column tile: columns >= J are pitch padding
+                if (js + 1 >= a.J) s1 = 0.f;
+                if (js + 2 >= a.J) s2 = 0.f;
+                if (js + 3 >= a.J) s3 = 0.f;
+                if (jl + 1 >= a.J) l1 = 0.f;
+                if (jl + 2 >= a.J) l2 = 0.f;
+                if (jl + 3 >= a.J) l3 = 0.f;
+            }
+            const int row = r8 + 32 * i;
+            uint2 hi, lo;
+            split4(s0, s1, s2, s3, hi, lo);
+            *(uint2*)&Ssm[0][row][4 * q] = hi;
+            *(uint2*)&Ssm[1][row][4 * q] = lo;
+            split4(l0, l1, l2, l3, hi, lo);
+            *(uint2*)&Lsm[0][row][4 * q] = hi;
+            *(uint2*)&Lsm[1][row][4 * q] = lo;
+        }
+    };
+
+    if (nsteps > 0) load_step(0);
+    for (int step = 0; step < nsteps; ++step) {
+        store_step(step);
+        __syncthreads();
+        if (step + 1 < nsteps) load_step(step + 1);
+        const unsigned short* Ah = &Ssm[0][wm * 64 + l31][half * 8];
+        const unsigned short* Al = &Ssm[1][wm * 64 + l31][half * 8];
+        const unsigned short* Bh = &Lsm[0][wn * 64 + l31][half * 8];
+        const unsigned short* Bl = &Lsm[1][wn * 64 + l31][half * 8];
+#pragma unroll
+        for (int kc = 0; kc < PWJ / 16; ++kc) {
+            bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *(const bf16x8_t*)(Ah + i * 32 * BW_PITCH + kc * 16);
+                al[i] = *(const bf16x8_t*)(Al + i * 32 * BW_PITCH + kc * 16);
+                bh[i] = *(const bf16x8_t*)(Bh + i * 32 * BW_PITCH + kc * 16);
+                bl[i] = *(const bf16x8_t*)(Bl + i * 32 * BW_PITCH + kc * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    f32x16 c = acc[i][n];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[n], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[n], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[n], c, 0, 0, 0);
+                    acc[i][n] = c;
+                }
+        }
+        __syncthreads();
+    }
+    float* P = a.part + (size_t)split * a.SpPad * a.LpPad;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int sp = sp0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int lp = lp0 + wn * 64 + n * 32 + l31;
+                P[(size_t)sp * a.LpPad + lp] = acc[i][n][r];
+            }
+}
+
 }  // namespace
 
 extern "C" long long idv_cconv_wgrad_bf16_work_floats(int Cs, int Cl, int B, int Tp) {
@@ -264,5 +389,27 @@ extern "C" int idv_cconv2d_bwd_weight_bf16x3(const float* x, int Cx, int ci_off,
     else
         hipLaunchKernelGGL(wgrad_bf16_kernel<-1>, dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
     launch_wgrad_unpack_conv(work, p.nsplit, p.SpPad, p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im, st);
+    return idv_launch_status();
+}
+
+// idv_pw_bwd_weight in split-bf16 arithmetic (bf16x3 training mode); arguments and work size as there
+extern "C" int idv_pw_bwd_weight_bf16x3(const float* dout, int M, int Jp_d, const float* x, int K, int Jp_x, int J, int shift,
+                                        float* work, long long work_floats, float* dw, int ldw, int rowmap, int H, int accumulate,
+                                        void* stream) {
+    if (!dout || !x || !work || !dw || M <= 0 || K <= 0 || J <= 0 || ldw < K || (shift != 0 && shift != -1)) return IDV_EINVAL;
+    if ((Jp_d % 4) || (Jp_x % 4) || !aligned16(dout) || !aligned16(x) || Jp_d < J || Jp_x < J) return IDV_EINVAL;
+    if (rowmap == 1 && (H <= 0 || (H % 16) || M % (4 * H))) return IDV_EINVAL;
+    if ((size_t)M * Jp_d * 4 >= 0x7ffffff0ull || (size_t)K * Jp_x * 4 >= 0x7ffffff0ull)
+        return idv_pw_bwd_weight(dout, M, Jp_d, x, K, Jp_x, J, shift, work, work_floats, dw, ldw, rowmap, H, accumulate, stream);
+    WgradArgs a{};
+    a.S = dout; a.Sp = M; a.Fs = 1; a.JpS = Jp_d;
+    a.L = x;    a.Lp = K; a.Fl = 1; a.JpL = Jp_x;
+    a.dt0 = shift; a.J = J;
+    const Plan p = make_plan(M, K, J, PW_MS, PW_ML, PWJ);
+    if ((long long)p.nsplit * p.SpPad * p.LpPad > work_floats) return IDV_EINVAL;
+    a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles; a.jt_per_split = p.jt_per_split;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_pw_bf16_kernel, dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
+    launch_wgrad_unpack_plain(work, p.nsplit, p.SpPad, p.LpPad, M, K, ldw, rowmap, H, accumulate, dw, st);
     return idv_launch_status();
 }

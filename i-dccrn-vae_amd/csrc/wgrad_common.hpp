@@ -47,3 +47,6 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // sums the split-K partial tiles in a fixed order and folds the four real products of a complex pair into (dW_re, dW_im)
 void launch_wgrad_unpack_conv(const float* part, int nsplit, int SpPad, int LpPad, int Cout, int Cx, int Cin_total, int ci_off,
                               int transposed, float* dw_re, float* dw_im, hipStream_t st);
+// out[rowmap(m)][k] (+)= sum over the split-K partial tiles; rowmap 1: LSTM gate order (colp -> g*H + u)
+void launch_wgrad_unpack_plain(const float* part, int nsplit, int SpPad, int LpPad, int M, int K, int ldw, int rowmap, int H,
+                               int accumulate, float* dw, hipStream_t st);

@@ -899,7 +899,9 @@ def pw_wgrad(dout_ptr, M: int, Jp_d: int, x_ptr, K: int, Jp_x: int, J: int, dw: 
              accumulate=False):
     n = int(_ll_fn("idv_pw_wgrad_work_floats")(i(M), i(K), i(J)))
     work = _scratch(n, dw.device)
-    call("idv_pw_bwd_weight", dout_ptr, i(M), i(Jp_d), x_ptr, i(K), i(Jp_x), i(J), i(shift), p(work), ll(work.numel()), p(dw),
+    # bf16x3 training mode: the split-bf16 kernel for the big contractions (LSTM projections); tiny ones stay fp32
+    bf16 = PRECISION == "bf16x3" and WGRAD_BF16 and M >= 64 and K >= 64
+    call("idv_pw_bwd_weight_bf16x3" if bf16 else "idv_pw_bwd_weight", dout_ptr, i(M), i(Jp_d), x_ptr, i(K), i(Jp_x), i(J), i(shift), p(work), ll(work.numel()), p(dw),
          i(dw.stride(0)), i(rowmap), i(H), i(1 if accumulate else 0), stream_ptr())
 
 

@@ -339,6 +339,9 @@ int idv_cconv2d_bwd_bias(const double* stats_dy, int Cout, float* db_re, float* 
 long long idv_pw_wgrad_work_floats(int M, int K, int J);
 int idv_pw_bwd_weight(const float* dout, int M, int Jp_d, const float* x, int K, int Jp_x, int J, int shift, float* work,
                       long long work_floats, float* dw, int ldw, int rowmap, int H, int accumulate, void* stream);
+/* the same contraction in split-bf16 arithmetic (bf16x3 training mode: LSTM projection, dense and DFT weight gradients) */
+int idv_pw_bwd_weight_bf16x3(const float* dout, int M, int Jp_d, const float* x, int K, int Jp_x, int J, int shift, float* work,
+                             long long work_floats, float* dw, int ldw, int rowmap, int H, int accumulate, void* stream);
 int idv_planar_rowsum(const float* x, int M, int Jp, int J, int accumulate, float* out, void* stream);   /* bias gradients */
 
 /* Train-mode ComplexBatchNormal + PReLU (complex_progress.py:131-209, pvae_module.py:64-68, :88-93).
