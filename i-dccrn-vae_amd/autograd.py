@@ -291,8 +291,18 @@ class LstmFn(torch.autograd.Function):
         flags = 4
         if ops.PRECISION == "bf16x3" and (H == 128 or (ops.LSTM_PERSISTENT and L.lib().idv_lstm_pers_supported(i(H), i(x.B)))):
             flags |= 1
+        wih1_16 = None
+        if flags & 1:
+            # input projections on the bf16 MFMA as in eval: layer 0 from the K-major split image of x, layer 1 from the
+            # image of h0 the persistent recurrence writes (H = 384 / 768)
+            if p0[3] is not None:
+                kimg = ops.KImage.from_planes(x.ptr(), 2 * K, x.B * x.Tp, x.Jp, xbuf.device)
+                call("idv_lstm_proj_bf16x3", kimg.ptr(), ll(kimg.lo_slots), i(K), p(p0[3]), p(p0[1]), p(work), i(H), i(x.B), i(x.T),
+                     i(x.Tp), i(x.Jp), stream_ptr())
+                flags |= 2
+            wih1_16 = p1[3]
         call("idv_clstm_fwd", x.ptr(), i(K), p(p0[0]), p(p0[1]), p(p0[2]), p(p1[0]), p(p1[1]), p(p1[2]), i(H), i(x.B), i(x.T),
-             i(x.Tp), i(x.Jp), p(work), out.ptr(), i(flags), p(None), stream_ptr())
+             i(x.Tp), i(x.Jp), p(work), out.ptr(), i(flags), p(wih1_16), stream_ptr())
         ctx.save_for_backward(xbuf, work, *params)
         ctx.mod, ctx.geom, ctx.ogeom = mod, geom, _geom(out)
         return out.buf
@@ -335,9 +345,14 @@ class LstmFn(torch.autograd.Function):
         h1p = [planar_of_rows(h1[r * TBH:(r + 1) * TBH], H, 0, H) for r in range(4)]
         dwih1, dwhh1, db1 = new(8 * H, H), new(8 * H, H), new(8 * H)
         dh0 = new(4 * TBH)
+        # bf16x3 training mode: the two data-gradient contractions of the projections (dh0 = dG1 W_ih1, dx = dG0 W_ih0) on the
+        # split-bf16 point-wise kernel, fed with K-major split images of the gate gradients (the fp32 form was 17 % of the
+        # NSVAE train step)
+        bf16 = ops.PRECISION == "bf16x3" and (4 * H) % 64 == 0 and H >= 64
+        zb = torch.zeros(max(H, K), dtype=torch.float32, device=dev) if bf16 else None
         for s in range(2):
             w_colp_T = P[f"{'lstm_im' if s else 'lstm_re'}.weight_ih_l1"][perm].t().contiguous()     # [H][4H colp]
-            wT = ops.pack_pw(w_colp_T, None)
+            wT = ops.pack_pw_bf16(w_colp_T) if bf16 else ops.pack_pw(w_colp_T, None)
             for k, run in enumerate((s, 2 + s)):
                 dG1p = planar_of_rows(G1[run * 4 * TBH:(run + 1) * 4 * TBH], 4 * H, 0, 4 * H)
                 acc = k > 0
@@ -347,7 +362,11 @@ class LstmFn(torch.autograd.Function):
                              accumulate=acc)
                 call("idv_lstm_bias_grad", p(dG1p), i(H), i(Jp), i(J), i(1 if acc else 0), p(db1[s * 4 * H:(s + 1) * 4 * H]), st())
                 # gradient arriving at layer 0's output: dG1 W_ih1, written row-major [T*B][H]
-                ops.pw_gemm(p(dG1p), 4 * H, wT[0], wT[1], H, B, Tp, Jp, T, p(dh0[run * TBH:(run + 1) * TBH]), swap=True, ldo=H)
+                if bf16:
+                    kimg = ops.KImage.from_planes(p(dG1p), 4 * H, J, Jp, dev, pad_to=64)
+                    ops.pw_bf16x3_rows(kimg, 4 * H, wT, zb, H, H, B, T, Tp, p(dh0[run * TBH:(run + 1) * TBH]))
+                else:
+                    ops.pw_gemm(p(dG1p), 4 * H, wT[0], wT[1], H, B, Tp, Jp, T, p(dh0[run * TBH:(run + 1) * TBH]), swap=True, ldo=H)
         # ---- layer 0
         call("idv_lstm_bptt", p(G0), ll(T * B * 8 * H), ll(4 * H), i(8 * H), p(c0), p(dh0), p(whhT(0)), i(H), i(B), i(T),
              p(bw), st())
@@ -355,7 +374,7 @@ class LstmFn(torch.autograd.Function):
         dx = ops.like(x) if ctx.needs_input_grad[2] else None
         if dx is not None:
             wcat = torch.cat([P["lstm_re.weight_ih_l0"][perm], P["lstm_im.weight_ih_l0"][perm]], 0)   # [8H colp][K]
-            wT0 = ops.pack_pw(wcat.t().contiguous(), None)
+            wT0 = ops.pack_pw_bf16(wcat.t().contiguous()) if bf16 else ops.pack_pw(wcat.t().contiguous(), None)
         for z in range(2):
             dG0p = planar_of_rows(G0[z * 8 * TBH:(z + 1) * 8 * TBH], 8 * H, 0, 8 * H)                # [s][4H colp] planes
             ops.pw_wgrad(p(dG0p), 8 * H, Jp, x.ptr(z * x.C), K, Jp, J, dwih0, rowmap=1, H=H, accumulate=z > 0)
@@ -364,7 +383,10 @@ class LstmFn(torch.autograd.Function):
                 ops.pw_wgrad(p(sl), 4 * H, Jp, p(h0p[2 * z + s]), H, Jp, J, dwhh0[s * 4 * H:(s + 1) * 4 * H], shift=-1, rowmap=1,
                              H=H, accumulate=z > 0)
                 call("idv_lstm_bias_grad", p(sl), i(H), i(Jp), i(J), i(1 if z > 0 else 0), p(db0[s * 4 * H:(s + 1) * 4 * H]), st())
-            if dx is not None:
+            if dx is not None and bf16:
+                kimg = ops.KImage.from_planes(p(dG0p), 8 * H, J, Jp, dev, pad_to=64)
+                ops.pw_bf16x3(kimg, 0, 8 * H, wT0, None, K, B, Tp, T, dx.ptr(z * x.C))
+            elif dx is not None:
                 ops.pw_gemm(p(dG0p), 8 * H, wT0[0], wT0[1], K, B, Tp, Jp, T, dx.ptr(z * x.C))
         grads = {}
         for s, m in enumerate(("lstm_re", "lstm_im")):

@@ -596,7 +596,8 @@ int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
     if ((flags & 1) && !(flags & 8) && cstate && idv_lstm_pers_supported(ra.H, ra.B)) {
         // H = 384 / 768 (VAE encoders), split-bf16 mode: one persistent cooperative launch per layer (lstm_pers.hip);
         // its exchange buffer lives in the scratch behind cstate (idv_clstm_work_floats covers it: 4*H*Jp floats)
-        return idv_lstm_rec_pers(ra.g, ra.g_run_z, ra.g_run_s, ra.ldg, ra.whh, ra.kimg ? nullptr : ra.hout, ra.H, ra.B, ra.T,
+        // the fp32 rows of h are skipped when the next projection reads the split image -- unless backward needs them (gsave)
+        return idv_lstm_rec_pers(ra.g, ra.g_run_z, ra.g_run_s, ra.ldg, ra.whh, (ra.kimg && !ra.gsave) ? nullptr : ra.hout, ra.H, ra.B, ra.T,
                                  (void*)(cstate + 4LL * ra.B * ra.H), ra.kimg, ra.kimg_lo, ra.Tp, ra.Jp, ra.gsave, ra.csave, (void*)st);
     }
     if (ra.H == 128 && (flags & 1)) {
@@ -653,7 +654,7 @@ extern "C" long long idv_clstm_work_floats(int H, int B, int T, int Jp) {
 // training (flags bit 2): both layers' gate buffers and the cell states are kept for the backward pass
 //   [G0 16TBH | G1 16TBH | h0 4TBH | h1 4TBH | c0 4TBH | c1 4TBH | cstate 4BH | hp 4*H*Jp]
 extern "C" long long idv_clstm_train_work_floats(int H, int B, int T, int Jp) {
-    return 48LL * T * B * H + 4LL * B * H + hp_floats(H, B, Jp);
+    return 48LL * T * B * H + 4LL * B * H + hp_floats(H, B, Jp) + 4LL * H * Jp;      // + split image of h0 (bf16x3 mode)
 }
 
 extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
@@ -685,7 +686,7 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     }
     // split-bf16 mode with the persistent recurrence and bf16 fragments of W_ih1: layer 0 writes h0 as the K-major split
     // image the bf16 point-wise kernel reads, no fp32 h0, no transpose (was: fp32 PW contraction, 14 % of the NSVAE step)
-    const bool img1 = (flags & 1) && !(flags & 8) && !save && wih1_bf16 && idv_lstm_pers_supported(H, B) &&
+    const bool img1 = (flags & 1) && !(flags & 8) && wih1_bf16 && idv_lstm_pers_supported(H, B) &&
                       idv_lstm_proj_bf16_supported(H, H) && (4 * H) % 256 == 0;
     float* hp = cstate + 4LL * B * H;                  // [4 runs][H][Jp] (per-step path) / exchange buffer (persistent path)
     void* himg = (void*)(hp + hp_floats(H, B, Jp));    // [hi | lo][4 runs][H/8][Jp] x 16 B

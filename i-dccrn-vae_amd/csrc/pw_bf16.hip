@@ -447,6 +447,24 @@ extern "C" int idv_pw_bf16x3(const void* ximg, long long lo_off_slots, int K, co
     return eff(64) > eff(128) + 0.02 ? launch_pw<2, 1, false>(a, st) : launch_pw<4, 1, false>(a, st);
 }
 
+// idv_pw_bf16x3 with the transposed store of the LSTM gate layout: out[(t * B + b) * ldo + m] for the valid (t, b) -- the
+// gradient arriving at a layer's output, dh = W^T dG, in the row-major form idv_lstm_bptt reads (bf16x3 training mode)
+extern "C" int idv_pw_bf16x3_rows(const void* ximg, long long lo_off_slots, int K, const void* wfrag_bf16, const float* bias,
+                                  float* out_rows, int M, int ldo, int B, int T, int Tp, int Jp, void* stream) {
+    if (!ximg || !wfrag_bf16 || !bias || !out_rows || K <= 0 || M <= 0 || ldo < M || B <= 0 || T <= 0 || Tp < T + 1 || Jp < B * Tp ||
+        (reinterpret_cast<uintptr_t>(ximg) & 15))
+        return IDV_EINVAL;
+    PwBf16Args a{};
+    const int Kp = (K + 63) / 64 * 64;
+    a.ximg = (const u32x4*)ximg; a.lo_off = lo_off_slots; a.KO = Kp / 8; a.part_stride = 0;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.t_valid = T; a.nB = B;
+    a.wfrag = (const uint4*)wfrag_bf16; a.bias = bias; a.out = out_rows; a.out_part_stride = 0; a.ldo = ldo; a.M = M;
+    const long long mb = (M + 255) / 256;
+    auto eff = [&](int jt) { const long long n = ((a.J + jt - 1) / jt) * mb; return (double)n / (double)(((n + 255) / 256) * 256); };
+    hipStream_t st = (hipStream_t)stream;
+    return eff(64) > eff(128) + 0.02 ? launch_pw<2, 1, true>(a, st) : launch_pw<4, 1, true>(a, st);
+}
+
 extern "C" int idv_stft_frames_kimage(const float* x, int B, int L, int n_fft, int win, int hop, int T, void* img, long long lo_off,
                                       int Tp, int Jp, void* stream) {
     if (!x || !img || B <= 0 || L <= n_fft / 2 || T != 1 + L / hop || Tp < T + 1 || Jp < B * Tp || (lo_off % 8)) return IDV_EINVAL;

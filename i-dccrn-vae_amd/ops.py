@@ -185,6 +185,12 @@ def pw_bf16x3(kimg: KImage, octet0: int, K: int, wfrag16, bias, M: int, B: int, 
          i(t_valid), stream_ptr())
 
 
+def pw_bf16x3_rows(kimg: KImage, K: int, wfrag16, bias, M: int, ldo: int, B: int, T: int, Tp: int, out_ptr):
+    """out[(t*B + b)*ldo + m] = sum_k W[m][k] x[k][(b, t)] + bias[m] over the valid frames (row-major, as idv_lstm_bptt reads)."""
+    call("idv_pw_bf16x3_rows", kimg.ptr(), ll(kimg.lo_slots), i(K), p(wfrag16), p(bias), out_ptr, i(M), i(ldo), i(B), i(T), i(Tp),
+         i(kimg.Jp), stream_ptr())
+
+
 def _dev_scratch(n: int, device, dtype=torch.float32, zero=False):
     return (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=device)
 

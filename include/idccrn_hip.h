@@ -229,7 +229,7 @@ void idv_lstm_pers_set_profile(unsigned long long* prof_cycles);
  *   [G0 16 TBH | G1 16 TBH | h0 4 TBH | h1 4 TBH | c0 4 TBH | c1 4 TBH | scratch]
  * G0: [z][T*B][8H] (z = real / imag input; columns [weight set s][4H]), G1: [run = 2z+s][T*B][4H], h/c: [run][T*B][H];
  * gate columns are ordered colp = ((u/16)*4 + gate)*16 + u%16. */
-long long idv_clstm_train_work_floats(int H, int B, int T, int Jp);   /* 48*T*B*H + 4*B*H + scratch(H, B, Jp) */
+long long idv_clstm_train_work_floats(int H, int B, int T, int Jp);   /* 48*T*B*H + 4*B*H + scratch(H, B, Jp) + 4*H*Jp */
 /* wih1_bf16 (may be NULL): idv_pack_lstm_ih_bf16 of layer 1; with it, flags bit 0 and the persistent recurrence, layer 0
  * hands h0 to the layer-1 projection as a split image (idv_lstm_proj1_bf16x3) instead of fp32 rows. */
 int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0, const float* wih1,
@@ -251,6 +251,10 @@ int idv_planar_to_kimage(const float* x, int nvalid, int nplanes, int J, int Jp,
  * ComplexDense (complex_progress.py:83-89).  ximg: K-major split image with K rounded up to 64 planes
  * (idv_planar_to_kimage with nplanes = that, or idv_stft_frames_kimage = idv_stft_frames writing the image directly);
  * wfrag: idv_pack_pw_bf16 of the row-major [M][K] matrix (idv_pw_bf16_wfrag_bytes). */
+/* the same contraction with the row-major transposed store out[(t*B + b)*ldo + m] over the valid (t, b): dh = W^T dG in the
+ * form idv_lstm_bptt reads (bf16x3 training mode) */
+int idv_pw_bf16x3_rows(const void* ximg, long long lo_off_slots, int K, const void* wfrag_bf16, const float* bias, float* out_rows,
+                       int M, int ldo, int B, int T, int Tp, int Jp, void* stream);
 long long idv_pw_bf16_wfrag_bytes(int M, int K);
 int idv_pack_pw_bf16(const float* w, int M, int K, void* wfrag, void* stream);
 int idv_pw_bf16x3(const void* ximg, long long lo_off_slots, int K, const void* wfrag_bf16, const float* bias, float* out, int M,

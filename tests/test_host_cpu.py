@@ -43,7 +43,7 @@ def test_lstm_scratch_covers_the_cooperative_exchange_buffers(amd):
         assert need > 0
         TBH = T * B * H
         scratch_eval = lib.idv_clstm_work_floats(I(H), I(B), I(T), I(Jp)) - (24 * TBH + 4 * B * H + 4 * H * Jp)
-        scratch_train = lib.idv_clstm_train_work_floats(I(H), I(B), I(T), I(Jp)) - (48 * TBH + 4 * B * H)
+        scratch_train = lib.idv_clstm_train_work_floats(I(H), I(B), I(T), I(Jp)) - (48 * TBH + 4 * B * H + 4 * H * Jp)
         assert 4 * scratch_eval >= need and 4 * scratch_train >= need, (H, B, T, Jp, scratch_eval, scratch_train, need)
         assert scratch_eval >= 4 * H * Jp and scratch_train >= 4 * H * Jp
 
