@@ -40,13 +40,14 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
 
 // D = +1 (dt0 == 0) or -1 (dt0 == -1): direction of the shifted copy of the L tile.
 // Staging goes through raw buffer loads: an invalid slot (plane or frequency row outside the tensor, column >= J) gets the
-// byte offset 0x80000000 (beyond the tensor), which the hardware answers with zeros -- no per-element masks (they were 2/3 of the 620 vector
-// instructions per step that bounded the first version at 190 TFLOP/s).  Needs tensors below 2 GB (host-checked).
+// byte offset 0xffffff00 (beyond the tensor), which the hardware answers with zeros -- no per-element masks (they were 2/3 of the 620 vector
+// instructions per step that bounded the first version at 190 TFLOP/s).  Needs tensors below 4 GB (host-checked; an offset of
+// 0xffffffff wraps in the hardware's range check and reads memory: keep the marker a few hundred bytes below 2^32).
 template <int D>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a) {
     constexpr int Q4 = BW_JT / 4;                                       // float4 slots per row
     constexpr int NS4 = BW_MS * Q4 / 256, NL4 = BW_LROWS * Q4 / 256;    // 4, 5
-    constexpr unsigned OOB = 0x80000000u;       // beyond num_records (< 2 GB) and far from the 32-bit wrap of offset + size
+    constexpr unsigned OOB = 0xffffff00u;       // beyond num_records (< 4 GB - 512) and clear of the 32-bit wrap of offset + size
     __shared__ __attribute__((aligned(16))) unsigned short Ssm[2][BW_MS][BW_PITCH];          // [hi|lo]
     __shared__ __attribute__((aligned(16))) unsigned short Lsm[2][2][BW_LROWS][BW_PITCH];    // [aligned|shifted][hi|lo]
 
@@ -225,7 +226,7 @@ constexpr int PW_MS = 128, PW_ML = 128, PWJ = 32;
 
 __global__ __launch_bounds__(256, 2) void wgrad_pw_bf16_kernel(const WgradArgs a) {
     constexpr int Q4 = PWJ / 4;
-    constexpr unsigned OOB = 0x80000000u;
+    constexpr unsigned OOB = 0xffffff00u;
     __shared__ __attribute__((aligned(16))) unsigned short Ssm[2][PW_MS][BW_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short Lsm[2][PW_ML][BW_PITCH];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -374,8 +375,8 @@ extern "C" int idv_cconv2d_bwd_weight_bf16x3(const float* x, int Cx, int ci_off,
         a.dt0 = 0;
     }
     a.J = B * Tp;
-    // the buffer-load staging needs 31-bit byte offsets; larger tensors: the exact-fp32 kernel
-    if ((size_t)a.Sp * a.Fs * a.JpS * 4 >= 0x7ffffff0ull || (size_t)a.Lp * a.Fl * a.JpL * 4 >= 0x7ffffff0ull) {
+    // the buffer-load staging needs 32-bit byte offsets; larger tensors: the exact-fp32 kernel
+    if ((size_t)a.Sp * a.Fs * a.JpS * 4 >= 0xfffffe00ull || (size_t)a.Lp * a.Fl * a.JpL * 4 >= 0xfffffe00ull) {
         if (idv_cconv_wgrad_work_floats(transposed ? Cx : Cout, transposed ? Cout : Cx, B, Tp) > work_floats) return IDV_EINVAL;
         return idv_cconv2d_bwd_weight(x, Cx, ci_off, dy, Cout, Cin_total, transposed, tshift, Fin, B, Tp, Jp_x, Jp_dy, work,
                                       work_floats, dw_re, dw_im, stream);
@@ -399,7 +400,7 @@ extern "C" int idv_pw_bwd_weight_bf16x3(const float* dout, int M, int Jp_d, cons
     if (!dout || !x || !work || !dw || M <= 0 || K <= 0 || J <= 0 || ldw < K || (shift != 0 && shift != -1)) return IDV_EINVAL;
     if ((Jp_d % 4) || (Jp_x % 4) || !aligned16(dout) || !aligned16(x) || Jp_d < J || Jp_x < J) return IDV_EINVAL;
     if (rowmap == 1 && (H <= 0 || (H % 16) || M % (4 * H))) return IDV_EINVAL;
-    if ((size_t)M * Jp_d * 4 >= 0x7ffffff0ull || (size_t)K * Jp_x * 4 >= 0x7ffffff0ull)
+    if ((size_t)M * Jp_d * 4 >= 0xfffffe00ull || (size_t)K * Jp_x * 4 >= 0xfffffe00ull)
         return idv_pw_bwd_weight(dout, M, Jp_d, x, K, Jp_x, J, shift, work, work_floats, dw, ldw, rowmap, H, accumulate, stream);
     WgradArgs a{};
     a.S = dout; a.Sp = M; a.Fs = 1; a.JpS = Jp_d;

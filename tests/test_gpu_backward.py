@@ -91,6 +91,35 @@ def test_conv_block_grads_bf16x3(ops, pm, cp, transposed, cin, cout, F, T, B, sk
         ops.set_precision(keep)
 
 
+def test_wgrad_bf16_offsets_beyond_2_gib(ops):
+    """The split-bf16 weight-gradient kernel addresses its operands with 32-bit buffer offsets (out-of-range marker
+    0xffffff00): a 2.6 GB activation (the first blocks of the CVAE decoder at B x num_samples = 160) must take the kernel, not
+    its fp32 fallback, and agree with the exact-fp32 kernel."""
+    cx, cout, F, T, B = 32, 32, 129, 639, 125
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = ops.Planar.empty(cx, F, B, T, T + 1, "cuda")
+    dy = ops.Planar.empty(cout, (F - 1) // 2 + 1, B, T, T + 1, "cuda")
+    for t in (x, dy):
+        t.buf.normal_(generator=g)
+        pl = t.planes()
+        pl[..., 0] = 0.0                                   # guard columns
+    assert x.C * 2 * x.F * x.Jp * 4 > 2 ** 31 + 2 ** 28            # 2.6 GB of activation planes
+    outs = []
+    keep = ops.PRECISION
+    try:
+        for prec in ("fp32", "bf16x3"):
+            ops.set_precision(prec)
+            dwr = torch.zeros(cout, cx, 5, 2, device="cuda")
+            dwi = torch.zeros_like(dwr)
+            ops.cconv_wgrad(x, 0, dy, cout, cx, False, True, dwr, dwi)
+            torch.cuda.synchronize()
+            outs.append((dwr.cpu().double(), dwi.cpu().double()))
+    finally:
+        ops.set_precision(keep)
+    for a, b in zip(outs[0], outs[1]):
+        assert float((a - b).norm() / a.norm()) < 1e-4
+
+
 def _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, ftol, gtol):
     g = torch.Generator().manual_seed(3)
     dev = "cuda"
