@@ -375,6 +375,66 @@ def test_cooperative_recurrence_times_out_instead_of_hanging(ops, H, precision):
     assert torch.isfinite(good).all() and torch.equal(good, again)
 
 
+def test_image_writing_variants_are_bit_identical(ops):
+    """The fused forms added for the bf16x3 training mode against the two-pass forms they replace, bit for bit:
+    planar -> image with the batch repeat inside (idv_planar_to_image_repeat), the out-of-place BN apply + PReLU and the BN
+    backward apply that also write the split image of their result (idv_cbn_apply_prelu_to_img, idv_cbn_bwd_apply_img)."""
+    g = torch.Generator().manual_seed(3)
+    C, F, B, T = 8, 5, 3, 21
+    x = ops.Planar.from_tensor5(torch.randn(B, C, F, T, 2, generator=g).cuda())
+    # repeat inside the conversion
+    a = ops.to_image_repeat(x, 2)
+    b = ops.to_image(ops.repeat_batch(x, 2))
+    n = (2 * C + 7) // 8 * F * a.Jp * 8
+    off = ops.IMG_SLACK
+    assert a.Jp == b.Jp and torch.equal(a.buf[off:off + n], b.buf[off:off + n])
+    assert torch.equal(a.buf[off + a.lo_off:off + a.lo_off + n], b.buf[off + b.lo_off:off + b.lo_off + n])
+    # BN apply + PReLU
+    fold = (torch.randn(C, 6, generator=g) * 0.5).cuda()
+    slope = torch.tensor([0.25], device="cuda")
+    z0 = ops.cbn_apply_to(x, fold, slope)
+    z1, zi = ops.cbn_apply_to(x, fold, slope, want_image=True)
+    ref = ops.to_image(z0)
+    assert torch.equal(z0.planes(), z1.planes())
+    m = (2 * C + 7) // 8 * F * zi.Jp * 8
+    assert torch.equal(zi.buf[off:off + m], ref.buf[off:off + m])
+    assert torch.equal(zi.buf[off + zi.lo_off:off + zi.lo_off + m], ref.buf[off + ref.lo_off:off + ref.lo_off + m])
+    # BN backward apply
+    dz = ops.Planar.from_tensor5(torch.randn(B, C, F, T, 2, generator=g).cuda())
+    moments = torch.stack([torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1, 0.5 + torch.rand(C, generator=g),
+                           0.1 * torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)]).cuda()
+    gam = [(1 + 0.1 * torch.randn(C, generator=g)).cuda(), torch.randn(C, generator=g).cuda(), (1 + 0.1 * torch.randn(C, generator=g)).cuda()]
+    cnt = float(B * F * T)
+    r0 = ops.cbn_bwd(dz, x, fold, moments, gam, slope, cnt)
+    r1 = ops.cbn_bwd(dz, x, fold, moments, gam, slope, cnt, want_image=True)
+    dy0, (dy1, dyi) = r0[0], r1[0]
+    # the channel sums behind both calls are double-precision atomics (order-dependent in the last bits): 1e-6 between the
+    # calls, bit-exact between the planar result and the image of ONE call
+    assert relerr(dy1.planes().cpu(), dy0.planes().cpu()) < 1e-6
+    ref = ops.to_image(dy1)
+    assert torch.equal(dyi.buf[off:off + m], ref.buf[off:off + m])
+    assert torch.equal(dyi.buf[off + dyi.lo_off:off + dyi.lo_off + m], ref.buf[off + ref.lo_off:off + ref.lo_off + m])
+    for u, v in zip(r0[1:], r1[1:]):
+        assert relerr(v.cpu(), u.cpu()) < 1e-6
+
+
+def test_pw_bf16x3_rows_matches_the_fp32_swap_store(ops):
+    """idv_pw_bf16x3_rows (dh = W^T dG in BPTT's row-major form, bf16x3 training) against idv_pw_gemm with the transposed
+    store, same operands: 2e-5."""
+    g = torch.Generator().manual_seed(4)
+    K, M, B, T = 256, 96, 3, 37
+    w = (torch.randn(M, K, generator=g) * 0.1).cuda()
+    xp = ops.Planar.from_tensor5(torch.randn(B, K // 2, 1, T, 2, generator=g).cuda())        # K planes of Jp columns
+    wf = ops.pack_pw(w, None)
+    want = torch.zeros(T * B, M, device="cuda")
+    ops.pw_gemm(xp.ptr(), K, wf[0], wf[1], M, B, xp.Tp, xp.Jp, T, ops.L._P(want.data_ptr()), swap=True, ldo=M)
+    kimg = ops.KImage.from_planes(xp.ptr(), K, B * xp.Tp, xp.Jp, "cuda", pad_to=64)
+    got = torch.zeros(T * B, M, device="cuda")
+    ops.pw_bf16x3_rows(kimg, K, ops.pack_pw_bf16(w), torch.zeros(M, device="cuda"), M, M, B, T, xp.Tp, ops.L._P(got.data_ptr()))
+    torch.cuda.synchronize()
+    assert relerr(got.cpu(), want.cpu()) < 2e-5
+
+
 def amd_lib():
     import importlib
     return importlib.import_module("i-dccrn-vae_amd")._lib.lib()
