@@ -81,7 +81,7 @@ class ConvBlockFn(torch.autograd.Function):
                 bn.init_flag = False
             if ops.train_image_ok(cout) and y.Jp == x.Jp:
                 z, zimg = ops.cbn_apply_to(y, fold, slope, want_image=True)      # the next block reads the image
-                z.buf._idv_img = zimg
+                z.buf._idv_img, z.buf._idv_img_ver = zimg, z.buf._version
             else:
                 z = ops.cbn_apply_to(y, fold, slope)
             ctx.save_for_backward(xbuf, skipbuf, w_re, w_im, y.buf, fold, moments, g_rr, g_ri, g_ii, slope)
@@ -168,11 +168,13 @@ def _dgrad(dy: Planar, w_re, w_im, cout_adj: int, cin_adj: int, fwd_transposed: 
 
 
 def _image_of(buf: torch.Tensor, pl: Planar):
-    """Split image of an activation, cached on its buffer tensor (same lifetime as the activation itself)."""
+    """Split image of an activation, cached on its buffer tensor (same lifetime as the activation itself; dropped when a
+    torch-level in-place op has changed the buffer since)."""
     img = getattr(buf, "_idv_img", None)
-    if img is None or img.Jp != pl.Jp or img.C != pl.C or img.F != pl.F:
+    if img is None or getattr(buf, "_idv_img_ver", buf._version) != buf._version or img.Jp != pl.Jp or img.C != pl.C or img.F != pl.F:
         img = ops.to_image(pl)
         buf._idv_img = img
+    buf._idv_img_ver = buf._version
     return img
 
 
