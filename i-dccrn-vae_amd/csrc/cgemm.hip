@@ -19,7 +19,11 @@ int launch_vec(const CgemmArgs& a, hipStream_t st) {
     b.ftiles = (rows + FO_T - 1) / FO_T;
     b.mblocks = ((a.M + 31) / 32 + WM * MT_W - 1) / (WM * MT_W);
     const long long tiles = (long long)b.jtiles * b.ftiles;
-    const long long nblk = ((tiles + 7) / 8) * 8 * b.mblocks;
+    // transposed conv: all frequency tiles of a column block on ONE XCD (they share 2 of their 5 input rows through its L2):
+    // -27 % L2-miss traffic on dec1-3 at unchanged speed; the conv mode lost 1 % with it and keeps the tile-major order
+    static const bool map_ft = [] { const char* e = getenv("IDV_MAP_FT"); return !e || e[0] != '0'; }();
+    b.map_ft = (map_ft && MODE == IDV_TCONV) ? 1 : 0;
+    const long long nblk = b.map_ft ? (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks : ((tiles + 7) / 8) * 8 * b.mblocks;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
     dim3 grid((unsigned)nblk);
     auto k = cgemm_kernel<MODE, WM, WN, MT_W, FO_T, JC_W, CCK, SWAP, STATS, VEC>;

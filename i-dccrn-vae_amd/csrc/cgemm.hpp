@@ -47,6 +47,7 @@ struct CgemmArgs {
     int ldo;              // SWAP: row stride of out; rows are ordered (tp-1)*B + b
     int nB;               // SWAP: utterances (B)
     int jtiles, ftiles, mblocks;   // grid decomposition (filled by the launcher)
+    int map_ft;                    // 1: an XCD takes ALL frequency tiles of its column blocks (they share halo rows in L2)
     // split-bf16 image sources / destination (cgemm_bf16.hip, cgemm_c1.hip); x0 / x1 then point at image data
     long long lo_off0, lo_off1;    // hi -> lo plane distance of the x0 / x1 image, in 16-byte slots
     void* out_img;                 // optional image destination (besides or instead of `out`)
@@ -102,11 +103,25 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
     // and re-read from that XCD's L2 (speed only, never correctness).
     const int MB = a.mblocks, FTn = a.ftiles;
     const int bid = blockIdx.x;
-    const int grp = bid / (8 * MB), rem = bid - grp * (8 * MB);
-    const int tile = grp * 8 + (rem & 7);
-    const int mblk = rem >> 3;
-    if (tile >= a.jtiles * FTn) return;                     // padding blocks of the last group
-    const int jt = tile / FTn, ft = tile - jt * FTn;
+    int jt, ft, mblk;
+    if (a.map_ft) {
+        // super group = 8 column blocks (one per XCD) x FTn frequency tiles x MB row-tile blocks; on an XCD the MB blocks
+        // of a frequency tile are consecutive, then the next frequency tile of the SAME column block
+        const int per = 8 * MB * FTn;
+        const int sg = bid / per, rem = bid - sg * per;
+        const int v = rem >> 3;
+        jt = sg * 8 + (rem & 7);
+        ft = v / MB;
+        mblk = v - ft * MB;
+        if (jt >= a.jtiles) return;                         // padding blocks of the last super group
+    } else {
+        const int grp = bid / (8 * MB), rem = bid - grp * (8 * MB);
+        const int tile = grp * 8 + (rem & 7);
+        mblk = rem >> 3;
+        if (tile >= a.jtiles * FTn) return;                 // padding blocks of the last group
+        jt = tile / FTn;
+        ft = tile - jt * FTn;
+    }
     const int j0 = jt * JT;
     const int mt0 = (mblk * WM + wm) * MT_W;                // first 32-row tile of this wave
     const int fo0 = ft * FO_T;                              // CONV: first output row; TCONV: first m
