@@ -8,6 +8,7 @@
 // 8 channel planes x 4 columns (8 aligned float4), converts, and writes 4 + 4 ds_write_b128.
 // Weights: pre-split bf16 fragments [row tile][chunk][tap][hi|lo][lane] x 16 B, streamed from L2 through a
 // 5-tap register ring (4 taps of prefetch distance).
+#include <cstdlib>
 #include "bf16_common.hpp"
 #include "../../include/idccrn_hip.h"
 #include <stdlib.h>
@@ -60,11 +61,23 @@ __global__ __launch_bounds__(WM* WN * 64, ((FO_T == 3 && JC_W == 1 && MT_W == 1)
 
     const int MB = a.mblocks, FTn = a.ftiles;
     const int bid = blockIdx.x;
-    const int grp = bid / (8 * MB), rem = bid - grp * (8 * MB);
-    const int tile = grp * 8 + (rem & 7);
-    const int mblk = rem >> 3;
-    if (tile >= a.jtiles * FTn) return;
-    const int jt = tile / FTn, ft = tile - jt * FTn;
+    int jt, ft, mblk;
+    if (a.map_ft) {                                          // all frequency tiles of a column block on one XCD (cgemm.hpp)
+        const int per = 8 * MB * FTn;
+        const int sg = bid / per, rem = bid - sg * per;
+        const int v = rem >> 3;
+        jt = sg * 8 + (rem & 7);
+        ft = v / MB;
+        mblk = v - ft * MB;
+        if (jt >= a.jtiles) return;
+    } else {
+        const int grp = bid / (8 * MB), rem = bid - grp * (8 * MB);
+        const int tile = grp * 8 + (rem & 7);
+        mblk = rem >> 3;
+        if (tile >= a.jtiles * FTn) return;
+        jt = tile / FTn;
+        ft = tile - jt * FTn;
+    }
     const int j0 = jt * JT;
     const int mt0 = (mblk * WM + wm) * MT_W;                 // this wave's first 32-row tile
     const int fo0 = ft * FO_T;
@@ -486,7 +499,10 @@ int launch_bf16(const CgemmArgs& a, hipStream_t st) {
     b.ftiles = (rows + FO_T - 1) / FO_T;
     b.mblocks = ((a.M + 31) / 32 + WM * MT_W - 1) / (WM * MT_W);
     const long long tiles = (long long)b.jtiles * b.ftiles;
-    const long long nblk = ((tiles + 7) / 8) * 8 * b.mblocks;
+    // all frequency tiles of a column block on one XCD (cgemm.hpp): -25 % L2-miss traffic in both modes at unchanged speed
+    static const int map_ft = [] { const char* e = getenv("IDV_MAP_FT_BF16"); return e ? atoi(e) : 2; }();   // 0 off, 1: TCONV, 2: both
+    b.map_ft = ((map_ft == 1 && MODE == IDV_TCONV) || map_ft == 2) ? 1 : 0;
+    const long long nblk = b.map_ft ? (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks : ((tiles + 7) / 8) * 8 * b.mblocks;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
     auto k = cgemm_bf16_kernel<MODE, WM, WN, FO_T, JC_W, STATS, MT_W, IMGIN, AD>;
     if (smem > 64 * 1024 &&
