@@ -317,8 +317,9 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
     r = {
         "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
         "traffic": traffic,
-        "traffic_note": f"HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from the committed rocprofv3 --pmc passes ({tsrc}, "
-                        "same command and batch); null when the run differs from that command",
+        "traffic_note": f"memory-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB from the committed rocprofv3 --pmc passes "
+                        f"({tsrc}, same command and batch; the L2's fabric requests, Infinity-Cache hits included: DESIGN.md 5); "
+                        "null when the run differs from that command",
         "peak_note": ("dense bf16 MFMA peak; achieved counts ALGORITHMIC fp32 flops (4 real convs), the kernel executes 3 bf16 "
                       "MFMA products per algorithmic product" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
         "kernel": kernel_name(dom), "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
