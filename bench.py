@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: 4 s @ 16 kHz utterances/sec, forward + SI-SNR, DCCRN-CL, on N MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (WORLD_SIZE set:
+      this process is one rank), or plain `python bench.py --gpus N`: the process then starts that launcher as a child and
+      relays rank 0's JSON line (it touches no GPU itself).
 
 One step = one pass of the hot path over one batch of synthetic utterances resident in HBM:
   DCCRN_(causal, skips 012345, mask).forward(noisy, train=False)  ->  ete_train_se_loss([0,0,1]).final_ete_loss
@@ -261,6 +264,39 @@ def cpu_baseline(seconds_budget=20.0, train=False):
             "vs_reference_note": "build-container cross-check against the imported reference: BASELINE.md section 2"}
 
 
+def self_launch(n_gpus: int) -> int:
+    """Parent of an N-rank run started as `python bench.py --gpus N`: start `python -m torch.distributed.run` as a CHILD
+    process (one rank per GPU, rendezvous on 127.0.0.1), pass its stderr through, relay the ranks' stdout (rank 0 prints the
+    one JSON line) and return its exit code.  No GPU call and no exec in this process."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"self-launch: {' '.join(cmd)}")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    json_line = None
+    for line in proc.stdout:
+        line = line.rstrip("\n")
+        if line.startswith("{") and '"metric"' in line:
+            json_line = line
+        elif line:
+            print(line, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc == 0 and json_line is None:
+        log("self-launch: the ranks exited 0 without a JSON line")
+        return 1
+    if json_line is not None:
+        print(json_line, flush=True)
+    return rc
+
+
 TRAIN_WORKLOADS = ("dccrn_cl_train", "cvae_train", "nsvae_train", "twophase_train")
 
 
@@ -406,14 +442,20 @@ def main():
     if args.batch is None:
         args.batch = 32 if train else DEFAULT_BATCH
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It never touches the GPU (no torch import,
+        # no HIP call) and never exec()s: the N ranks are children of torch.distributed.run, rank 0's JSON line is relayed.
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ... "
+                         "(or unset WORLD_SIZE and let bench.py start the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -489,7 +531,10 @@ def main():
     if rank == 0:
         out = {
             "metric": METRIC, "value": round(value, 3), "unit": "utterances/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+            "backend": ((dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (rehearsal, no RCCL)"))
+                        if world > 1 else "none (single process)"),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16x3 (split-fp32 operands on bf16 MFMA, fp32 accumulate)",

@@ -29,6 +29,14 @@ def declared_symbols() -> list:
     return sorted(set(re.findall(r"\b(idv_[a-z0-9_]+)\s*\(", src)))
 
 
+def declared_abi_version() -> int:
+    with open(HEADER_PATH) as f:
+        m = re.search(r"#define\s+IDV_ABI_VERSION\s+(\d+)", f.read())
+    if not m:
+        raise IdvError("include/idccrn_hip.h does not define IDV_ABI_VERSION")
+    return int(m.group(1))
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
@@ -37,6 +45,12 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP hot path.")
         _lib = ctypes.CDLL(LIB_PATH)
+        want = declared_abi_version()
+        if not hasattr(_lib, "idv_abi_version") or int(_lib.idv_abi_version()) != want:
+            got = int(_lib.idv_abi_version()) if hasattr(_lib, "idv_abi_version") else None
+            _lib = None
+            raise IdvError(f"{LIB_PATH} has ABI version {got}, include/idccrn_hip.h declares {want}: rebuild it "
+                           "(`python __graft_entry__.py`)")
         for name in declared_symbols():
             if not hasattr(_lib, name):
                 if os.environ.get("IDV_DEV_PARTIAL_LIB"):
@@ -60,7 +74,10 @@ def call(name: str, *args):
     fn = getattr(lib(), name)
     rc = fn(*args)
     if rc != 0:
-        raise IdvError(f"{name} failed with status {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")
+        what = {-1: "invalid argument", -2: "launch failure",
+                -3: "an earlier cooperative recurrence timed out (a sibling workgroup never became resident); its outputs "
+                    "are NaN-poisoned, this call was not launched"}.get(rc, "?")
+        raise IdvError(f"{name} failed with status {rc} ({what})")
 
 
 class _TensorPtr(ctypes.c_void_p):

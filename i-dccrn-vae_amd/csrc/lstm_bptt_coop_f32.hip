@@ -7,10 +7,9 @@
 // nn.LSTM behind `loss.backward()` in the reference (model/complex_progress.py:50-74; supervised_dccrn/train.py:239-243).
 #include <cstdlib>
 #include "common.hpp"
+#include "coop.hpp"
 #include "../../include/idccrn_hip.h"
 
-int idv_coop_chain_begin(hipStream_t st);      // lstm_pers.hip: cooperative launches of one device are chained
-int idv_coop_chain_end(hipStream_t st);
 
 namespace idv_bcoop {
 
@@ -28,6 +27,7 @@ struct BCoopArgs {
     unsigned* sync;       // [abort flag: 256 B][group = run * tiles + tile][replica][256 B]
     int nrep;
     int B, T, Bpad, tiles;
+    unsigned* status;     // host-mapped sticky status word (coop.hpp) or nullptr
     int fault;
 };
 
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bptt_coop_f32_kernel(const BCoopA
     }
     if (aborted) {
         // poison this workgroup's gate gradients: a timed-out BPTT must never look like a result
+        if (tid == 0) idv_coop_raise(a.status);
         const float qnan = __builtin_nanf("");
         for (long long e = tid; e < (long long)a.T * 16 * 128; e += 256) {
             const int cidx = (int)(e & 127), br = (int)((e >> 7) & 15);
@@ -201,7 +202,7 @@ constexpr int SYNC_BYTES = 256 + 64 * 8 * 256;
 extern "C" int idv_lstm_bptt_coop_supported(int H, int B) {
     static const bool on = [] { const char* e = getenv("IDV_LSTM_BPTT_COOP"); return !e || e[0] != '0'; }();
     if (!on || H != 128 || B <= 0) return 0;
-    return 4 * 4 * ((B + 15) / 16) <= 240;
+    return 4 * 4 * ((B + 15) / 16) <= idv_coop_max_workgroups();      // every workgroup resident at once, one per CU
 }
 
 extern "C" long long idv_lstm_bptt_coop_work_bytes(int H, int B) {
@@ -228,6 +229,7 @@ extern "C" int idv_lstm_bptt_coop(float* gates, long long g_run_z, long long g_r
     a.nrep = 4;
     a.B = B; a.T = T; a.Bpad = (int)Bpad; a.tiles = tiles;
     { const char* e = getenv("IDV_COOP_FAULT"); a.fault = (e && e[0] == '1') ? 1 : 0; }
+    a.status = idv_coop_status_word();
     const size_t smem = 84 * 1024;                   // one workgroup per CU
     if (hipFuncSetAttribute((const void*)lstm_bptt_coop_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return IDV_ELAUNCH;

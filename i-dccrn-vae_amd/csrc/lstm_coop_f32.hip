@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <mutex>
 #include "common.hpp"
+#include "coop.hpp"
 #include "../../include/idccrn_hip.h"
 
 namespace idv_coop {
@@ -31,6 +32,7 @@ struct CoopArgs {
     unsigned* sync;           // [abort flag: 256 B][group = run * tiles + tile][replica][256 B]
     int nrep;
     int B, T, Bpad, tiles;
+    unsigned* status;         // host-mapped sticky status word (coop.hpp) or nullptr
     int fault;                // test hook (IDV_COOP_FAULT=1): workgroup (0, 0, 0) never arrives -> the bounded spins must abort
 };
 
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_f32_kernel(const CoopArgs a)
         if (tid < a.nrep) __hip_atomic_fetch_add(counter0 + (size_t)tid * 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (aborted) {
+        if (tid == 0) idv_coop_raise(a.status);
         const float qnan = __builtin_nanf("");
         for (long long e = tid; e < (long long)a.T * 16 * UPW; e += 256) {
             const int u = (int)(e % UPW), br = (int)((e / UPW) & 15);
@@ -187,15 +190,12 @@ constexpr int SYNC_BYTES = 256 + 64 * 8 * 256;      // abort flag + (<= 64 group
 
 }  // namespace idv_coop
 
-// cooperative launches of one device are chained (see lstm_pers.hip); the two kernels share the chain through this hook
-int idv_coop_chain_begin(hipStream_t st);
-int idv_coop_chain_end(hipStream_t st);
 
 extern "C" int idv_lstm_coop_f32_supported(int H, int B) {
     static const bool on = [] { const char* e = getenv("IDV_LSTM_COOP_F32"); return !e || e[0] != '0'; }();
     if (!on || H != 128 || B <= 0) return 0;
     const int tiles = (B + 15) / 16;
-    return 4 * 4 * tiles <= 240;                     // every workgroup resident at once, one per CU
+    return 4 * 4 * tiles <= idv_coop_max_workgroups();      // every workgroup resident at once, one per CU
 }
 
 extern "C" long long idv_lstm_coop_f32_work_bytes(int H, int B) {
@@ -223,6 +223,7 @@ extern "C" int idv_lstm_rec_coop_f32(const float* g, long long g_run_z, long lon
     a.nrep = 4;
     a.B = B; a.T = T; a.Bpad = (int)Bpad; a.tiles = tiles;
     { const char* e = getenv("IDV_COOP_FAULT"); a.fault = (e && e[0] == '1') ? 1 : 0; }
+    a.status = idv_coop_status_word();
     const size_t smem = 84 * 1024;                   // > half a CU's LDS: one workgroup per CU (red[] needs 32 KB)
     if (hipFuncSetAttribute((const void*)lstm_coop_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return IDV_ELAUNCH;

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <mutex>
 #include "common.hpp"
+#include "coop.hpp"
 #include "../../include/idccrn_hip.h"
 
 namespace idv_pers {
@@ -43,6 +44,7 @@ struct PersArgs {
     int nrep;                 // replicas of each arrive counter (1, 2, 4 or 8), each on a 256-byte block of its own
     int H, B, T, Bpad, nchunks;
     int fault;                // test hook (IDV_COOP_FAULT=1): workgroup (0, 0, 0) never arrives -> the bounded spins must abort
+    unsigned* status;         // host-mapped sticky status word (coop.hpp) or nullptr
     unsigned long long* prof; // diagnostic build only: [workgroup][8] accumulated phase cycles, [7] = XCC id
 };
 
@@ -278,7 +280,9 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
         a.prof[wg * 8 + 7] = __builtin_amdgcn_s_getreg(6164) & 15;      // HW_REG_XCC_ID (id 20, offset 0, size 4)
     }
     if (aborted) {
-        // poison this workgroup's outputs: a timed-out recurrence must never look like a result
+        // poison this workgroup's outputs: a timed-out recurrence must never look like a result; the host learns it through
+        // the sticky status word (the next cooperative entry / idv_coop_last_status returns IDV_ECOOP)
+        if (tid == 0) idv_coop_raise(a.status);
         const float qnan = __builtin_nanf("");
         for (int rt = 0; rt < NRT; ++rt) {
             if (!t_ok[rt]) continue;
@@ -295,8 +299,8 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_kernel(const PersArgs a) {
     }
 }
 
-// 16-row tiles per workgroup: as few as the residency bound allows (every workgroup must be resident at once: <= 240 of the
-// 256 CUs, one workgroup each).  The step is bound by each CU's read of h_{t-1} (rows x H x 4 bytes of freshly handed-off
+// 16-row tiles per workgroup: as few as the residency bound allows (every workgroup must be resident at once, one per CU:
+// idv_coop_max_workgroups(), 240 on a 256-CU MI355X).  The step is bound by each CU's read of h_{t-1} (rows x H x 4 bytes of freshly handed-off
 // data at ~20 bytes / cycle / CU) and by fixed hand-off latencies, so fewer rows per workgroup on more CUs is faster:
 // H = 384, B = 32: 1 tile (192 workgroups); H = 768, B = 32: 2 (192); H = 768, B = 64: 4 (192).
 inline int nrt_for(int H, int B) {
@@ -304,7 +308,7 @@ inline int nrt_for(int H, int B) {
     const int NT = 2 * ((B + 15) / 16);
     for (int nrt = 1; nrt <= 4; nrt *= 2) {
         if (forced > nrt) continue;
-        if (2 * (H / 16) * ((NT + nrt - 1) / nrt) <= 240) return nrt;
+        if (2 * (H / 16) * ((NT + nrt - 1) / nrt) <= idv_coop_max_workgroups()) return nrt;
     }
     return 0;
 }
@@ -324,18 +328,93 @@ extern "C" long long idv_lstm_pers_work_bytes(int H, int B) {
     return SYNC_BYTES + 2LL * 4 * Bpad * H * 4;       // [abort flag + arrive counters, zeroed per call][exchange]
 }
 
+// ---- per-device process state of the cooperative kernels (coop.hpp) ------------------------------------------------------
 // Two cooperative launches must never share the chip: each needs ALL its workgroups resident (it spins on its siblings), and
 // two half-resident launches on different streams would wait for each other until the spin bound poisons both.  Launches
 // from different streams of one device are therefore chained through an event (other kernels may still overlap them).
 static std::mutex g_pers_mu;
 static hipEvent_t g_pers_done[16] = {};
 static hipStream_t g_pers_stream[16] = {};
+static int g_max_wg[16] = {};                 // 0: not queried yet
+static unsigned* g_status_host[16] = {};      // host-mapped sticky status words
+static unsigned* g_status_dev[16] = {};
+static bool g_status_tried[16] = {};
 
-// begin: take the chain lock and make `st` wait for the previous cooperative launch of this device; end: record + release
-int idv_coop_chain_begin(hipStream_t st) {
+static int cur_dev() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return IDV_ELAUNCH;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
+    return dev;
+}
+
+extern "C" int idv_coop_max_workgroups(void) {
+    // no device visible (sizing queries in the build container): the MI355X figure, 256 CUs - 16
+    const int dev = cur_dev();
+    if (dev < 0) { (void)hipGetLastError(); return 240; }
+    std::lock_guard<std::mutex> lk(g_pers_mu);
+    if (g_max_wg[dev] == 0) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) {
+            (void)hipGetLastError();
+            g_max_wg[dev] = 240;
+        } else {
+            // one workgroup per CU (every cooperative launch requests > half a CU's LDS); 1/16 of the CUs stay free so that a
+            // kernel of another stream still finds a CU and never delays the start of a sibling workgroup indefinitely
+            const int cu = pr.multiProcessorCount;
+            int n = cu - cu / 16;
+            const char* e = getenv("IDV_COOP_MAX_WG");              // experiments / CU-masked devices
+            if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
+            g_max_wg[dev] = n;
+        }
+    }
+    return g_max_wg[dev];
+}
+
+unsigned* idv_coop_status_word() {
+    const int dev = cur_dev();
+    if (dev < 0) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pers_mu);
+    if (!g_status_tried[dev]) {
+        g_status_tried[dev] = true;
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 256, hipHostMallocMapped) == hipSuccess) {
+            *(volatile unsigned*)h = 0u;
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                g_status_host[dev] = (unsigned*)h;
+                g_status_dev[dev] = (unsigned*)d;
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    return g_status_dev[dev];
+}
+
+// IDV_ECOOP if a cooperative kernel of the current device has timed out since the status was last cleared (its outputs are
+// NaN-poisoned); clear != 0 resets it.  The word is written by the device when the kernel aborts, so a launch that is
+// still queued is not covered: synchronise the stream first for a definite answer.
+extern "C" int idv_coop_last_status(int clear) {
+    const int dev = cur_dev();
+    if (dev < 0) return IDV_ELAUNCH;
+    (void)idv_coop_status_word();
+    std::lock_guard<std::mutex> lk(g_pers_mu);
+    volatile unsigned* w = g_status_host[dev];
+    if (!w || !*w) return IDV_OK;
+    if (clear) *w = 0u;
+    return IDV_ECOOP;
+}
+
+int idv_coop_chain_begin(hipStream_t st) {
+    const int dev = cur_dev();
+    if (dev < 0) return IDV_ELAUNCH;
     g_pers_mu.lock();
+    volatile unsigned* w = g_status_host[dev];
+    if (w && *w) {                       // an earlier cooperative launch timed out: report it once, then carry on
+        *w = 0u;
+        g_pers_mu.unlock();
+        return IDV_ECOOP;
+    }
     if (g_pers_done[dev] && g_pers_stream[dev] != st && hipStreamWaitEvent(st, g_pers_done[dev], 0) != hipSuccess) {
         g_pers_mu.unlock();
         return IDV_ELAUNCH;
@@ -343,9 +422,8 @@ int idv_coop_chain_begin(hipStream_t st) {
     return IDV_OK;
 }
 int idv_coop_chain_end(hipStream_t st) {
-    int dev = 0;
-    int rc = IDV_OK;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) rc = IDV_ELAUNCH;
+    const int dev = cur_dev();
+    int rc = dev < 0 ? IDV_ELAUNCH : IDV_OK;
     if (!rc && !g_pers_done[dev] && hipEventCreateWithFlags(&g_pers_done[dev], hipEventDisableTiming) != hipSuccess) rc = IDV_ELAUNCH;
     if (!rc && hipEventRecord(g_pers_done[dev], st) != hipSuccess) rc = IDV_ELAUNCH;
     if (!rc) g_pers_stream[dev] = st;
@@ -407,22 +485,22 @@ extern "C" int idv_lstm_rec_pers(const float* g, long long g_run_z, long long g_
     // one measured for one workgroup per CU, and co-located workgroups would share one CU's miss bandwidth)
     size_t smem = (size_t)4 * nrt * 4 * 4 * 64 * sizeof(float);
     if (smem < 84 * 1024) smem = 84 * 1024;
-#define IDV_PERS_LAUNCH(KBW, NRT)                                                                                         \
-    do {                                                                                                                  \
-        auto k = prof ? lstm_pers_kernel<KBW, NRT, true> : lstm_pers_kernel<KBW, NRT, false>;                             \
-        if (smem > 48 * 1024 &&                                                                                           \
-            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)     \
-            return IDV_ELAUNCH;                                                                                           \
-        hipLaunchKernelGGL(k, grid, dim3(256), smem, st, a);                                                              \
-    } while (0)
+    a.status = idv_coop_status_word();
+    // the kernel is chosen and its LDS attribute set BEFORE the chain lock is taken: no early return may hold the lock
+    typedef void (*kern_t)(const PersArgs);
+    kern_t k = nullptr;
+#define IDV_PERS_PICK(KBW, NRT) k = prof ? (kern_t)lstm_pers_kernel<KBW, NRT, true> : (kern_t)lstm_pers_kernel<KBW, NRT, false>
+    if (H == 384) {
+        if (nrt == 1) IDV_PERS_PICK(3, 1); else if (nrt == 2) IDV_PERS_PICK(3, 2); else IDV_PERS_PICK(3, 4);
+    } else {
+        if (nrt == 1) IDV_PERS_PICK(6, 1); else if (nrt == 2) IDV_PERS_PICK(6, 2); else IDV_PERS_PICK(6, 4);
+    }
+#undef IDV_PERS_PICK
+    if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return IDV_ELAUNCH;
     int rc = idv_coop_chain_begin(st);
     if (rc) return rc;
-    if (H == 384) {
-        if (nrt == 1) IDV_PERS_LAUNCH(3, 1); else if (nrt == 2) IDV_PERS_LAUNCH(3, 2); else IDV_PERS_LAUNCH(3, 4);
-    } else {
-        if (nrt == 1) IDV_PERS_LAUNCH(6, 1); else if (nrt == 2) IDV_PERS_LAUNCH(6, 2); else IDV_PERS_LAUNCH(6, 4);
-    }
-#undef IDV_PERS_LAUNCH
+    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, a);
     if ((rc = idv_coop_chain_end(st))) return rc;
     return idv_launch_status();
 }

@@ -4,9 +4,13 @@
  * point below replaces the stock torch operator(s) behind one reference function (file:line cited
  * per entry, paths relative to the reference root).  Conventions:
  *   - every pointer is a DEVICE pointer (hipMalloc / torch.cuda memory) unless it says "host";
- *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it, never allocate,
- *     never synchronise, keep no global state (re-entrant across streams);
- *   - return value: 0 ok, -1 invalid argument, -2 launch failure; nothing throws;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it, never allocate device memory,
+ *     never synchronise and are re-entrant across streams.  The ONLY process state the library keeps belongs to the
+ *     cooperative recurrences (idv_lstm_rec_pers / _pers_f32 / _coop_f32, idv_lstm_bptt_coop / _pers): per device, the
+ *     CU count, an event that orders cooperative launches of different streams, and a 256-byte host-mapped status word
+ *     (see idv_coop_last_status);
+ *   - return value: 0 ok, -1 invalid argument, -2 launch failure, -3 (IDV_ECOOP) an EARLIER cooperative recurrence ran into
+ *     its spin bound (its outputs are NaN-poisoned); nothing throws;
  *   - activations use the planar-J layout  act[ri][C][F][Jp]  (fp32):
  *       column j = b*Tp + tp, Tp = T+1, tp = t+1, tp==0 and tp>t_valid are zero guard columns,
  *       Jp >= B*Tp is the row stride; buffers need IDV_SLACK floats of slack in front and behind.
@@ -19,10 +23,18 @@
 extern "C" {
 #endif
 
-#define IDV_ABI_VERSION 3
+#define IDV_ABI_VERSION 4
 #define IDV_SLACK_FLOATS 256
 
 int idv_abi_version(void);
+
+/* Sticky status of the cooperative recurrences on the current device: -3 if one of them has run into its spin bound (a sibling
+ * workgroup never became resident, e.g. on a CU-masked or shared GPU; its outputs were poisoned with NaN) since the status was
+ * last cleared, else 0.  clear != 0 resets it.  The next cooperative entry reports (and clears) the same condition by returning
+ * -3 without launching.  The word is written by the device: synchronise the stream first for a definite answer. */
+int idv_coop_last_status(int clear);
+/* Workgroups a cooperative launch may use on the current device: multiProcessorCount minus 1/16 head room (240 on MI355X). */
+int idv_coop_max_workgroups(void);
 
 /* ---- weight preparation (device -> device, run once per parameter update) ------------------ */
 

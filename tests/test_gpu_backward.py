@@ -372,9 +372,9 @@ def summarize(t, limit=16384, cap=8192):
     return t[::-(-t.numel() // cap)]
 
 
-def check_grads(d, prefix, module, tol=1e-3, tol1=None):
+def check_grads(d, prefix, module, tol=1e-3, tol1=None, errs=None):
     """Every parameter gradient of `module` against the reference's (summarised gradient + full L2 norm); tol1: tolerance
-    for one-element tensors (default tol)."""
+    for one-element tensors (default tol); errs: dict that receives the per-tensor error of every multi-element tensor."""
     n = 0
     worst = (0.0, "")
     lim = (int(d["sum_limit"]), int(d["sum_cap"])) if "sum_limit" in d.files else (16384, 8192)
@@ -400,6 +400,8 @@ def check_grads(d, prefix, module, tol=1e-3, tol1=None):
             assert abs(gn - wn) < tk * wn, f"{k}: norm {gn} vs {wn}"
             if p_.numel() > 1 or tol1 is None:
                 worst = max(worst, (err, k))
+                if errs is not None:
+                    errs[k] = err
         n += 1
     assert n > 0
     return worst
@@ -481,8 +483,30 @@ def test_grad_dccrn_reference_full_width(pm, losses, golden, ops, precision):
         assert abs(float(a) - float(b)) < 2e-4 * max(1.0, abs(float(b)))
     tol = 1e-2 if precision == "fp32" else 3e-2
     assert relerr(x.grad.cpu(), T_(d["gx"])) < tol
-    worst = check_grads(d, "", m, tol=tol, tol1=3 * tol)
+    errs = {}
+    worst = check_grads(d, "", m, tol=tol, tol1=3 * tol, errs=errs)
     print("worst parameter-gradient error vs the reference", worst)
+    # the per-tensor cap above has to cover the few tensors behind a flipped PReLU element; a kernel error would move ALL of
+    # them, so the DISTRIBUTION is held to the measured one + 2x (fp32: median 1.2e-4, 90 % below 8e-4 measured)
+    e = sorted(errs.values())
+    med, p90 = e[len(e) // 2], e[(9 * len(e)) // 10]
+    print(f"{precision}: {len(e)} tensors, median {med:.2e}, 90th percentile {p90:.2e}, max {e[-1]:.2e}")
+    _dump(f"grad_ref_full_{precision}", errs)
+    med_cap, p90_cap = FULL_REF_CAPS[precision]
+    assert med < med_cap and p90 < p90_cap, (med, p90)
+
+
+FULL_REF_CAPS = {"fp32": (1e-3, 4e-3), "bf16x3": (3e-3, 1e-2)}
+
+
+def _dump(name, obj):
+    """Per-tensor error tables for the profiles / tolerance bookkeeping (only when run on the GPU box by gpurun)."""
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, name + ".json"), "w") as f:
+            json.dump(obj, f, indent=0, sort_keys=True)
 
 
 def test_grad_cvae_reference(pm, losses, golden):
@@ -706,6 +730,7 @@ def _full_width(pm, nl):
     print(f"input gradient vs float64: HIP {ours:.2e}, float32 oracle {ref32:.2e}")
     assert ours < 1e-2
     n, worst = 0, (0.0, "", 0.0)
+    table, sq = {}, [0.0, 0.0, 0.0]
     for k, p_ in m.named_parameters():
         want = sd[k].grad
         if want is None:
@@ -718,7 +743,31 @@ def _full_width(pm, nl):
         # sample on either side, not an average over elements: 3e-2
         tol = 3e-2 if p_.numel() == 1 else 1e-2
         assert ours < tol, (k, ours, ref32)
+        # ... and the bar that is ASSERTED, not argued: per tensor the HIP path may deviate from float64 at
+        # most YARD_K times as far as the float32 oracle does (the PReLU-flip noise is an independent sample on either side),
+        # with a floor where the float32 oracle happens to be flip-free
+        k_, floor = YARD[ops_precision()]
+        if p_.numel() > 1:
+            assert ours <= max(k_ * ref32, floor), (k, ours, ref32)
+            wn = float(want.double().norm())
+            sq[0] += (ours * wn) ** 2
+            sq[1] += (ref32 * wn) ** 2
+            sq[2] += wn ** 2
+        table[k] = (ours, ref32)
         worst = max(worst, (ours, k, ref32))
         n += 1
     print("worst parameter gradient (HIP vs float64, name, float32 oracle vs float64)", worst)
     assert n > 100
+    # all multi-element parameter gradients as ONE vector: the flip noise averages out, a kernel error would not
+    tot_ours, tot_ref = (sq[0] / sq[2]) ** 0.5, (sq[1] / sq[2]) ** 0.5
+    print(f"whole gradient vector vs float64: HIP {tot_ours:.2e}, float32 oracle {tot_ref:.2e}")
+    _dump(f"grad_f64_full_{ops_precision()}", {"table": table, "total": [tot_ours, tot_ref]})
+    assert tot_ours <= max(YARD[ops_precision()][0] * tot_ref, 1e-3), (tot_ours, tot_ref)
+
+
+YARD = {"fp32": (3.0, 1e-3), "bf16x3": (10.0, 3e-3)}
+
+
+def ops_precision():
+    import importlib
+    return importlib.import_module("i-dccrn-vae_amd").ops.PRECISION

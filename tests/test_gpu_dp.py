@@ -58,30 +58,131 @@ def _train_step(rank, world):
             {k: float(v.grad.double().norm()) for k, v in params.items() if v.grad is not None})
 
 
-def _worker(rank, world, port, q):
+ZDIM, NS, BG, LG = 8, 2, 4, 1600          # zdim 8 -> LSTM hidden 24 (CVAE / NVAE encoders) and 48 (noisy encoder, latent_num 2)
+
+
+def _load(module, seed):
+    module.load_state_dict(O.synth_state_dict({k: tuple(v.shape) for k, v in module.state_dict().items()}, seed))
+    return module.cuda()
+
+
+def _vae_inputs(par, rank, world, n_eps):
+    g = torch.Generator().manual_seed(11)
+    clean = torch.randn(BG, LG, generator=g) * 0.1
+    noise = torch.randn(BG, LG, generator=g) * 0.05
+    T = 1 + LG // HOP
+    eps = [torch.randn(BG, NS, T, ZDIM, generator=g) for _ in range(n_eps)]
+    sh = lambda t: par.shard(t, rank, world).cuda()
+    return sh(clean), sh(noise), [sh(e) for e in eps]
+
+
+def _collect(loss, module, keys, bufs):
+    torch.cuda.synchronize()
+    params = dict(module.named_parameters())
+    sd = module.state_dict()
+    return (float(loss.detach()), {k: params[k].grad.cpu().numpy() for k in keys}, {k: sd[k].cpu().numpy() for k in bufs},
+            {k: float(v.grad.double().norm()) for k, v in params.items() if v.grad is not None})
+
+
+NS_KEYS = ("encoders.0.conv.conv_re.weight", "encoders.2.bn.gamma_ri", "encoders.5.prelu.weight", "encoders.4.conv.conv_im.weight",
+           "lstms.0.lstm_re.weight_ih_l0", "lstms.0.lstm_im.weight_hh_l1", "lstms.0.lstm_re.bias_hh_l0")
+NS_BUFS = ("encoders.1.bn.Vri", "encoders.3.bn.running_mean_imag", "encoders.5.bn.Vrr")
+
+
+def _nsvae_step(rank, world):
+    """BASELINE config 4 per rank (train_nsvae.py:487-574): frozen clean / noise encoders in eval mode under no_grad, the
+    trainable noisy encoder (latent_num = 2: H = 6 zdim) in train mode with Sync-CBN, nsvae KL loss, backward, averaging."""
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    nl = importlib.import_module("i-dccrn-vae_amd.model.nsvae_loss")
+    par = importlib.import_module("i-dccrn-vae_amd.parallel")
+    np_ = O.net_params(True, 4)
+    ce = _load(pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cuda", ZDIM, NFFT, HOP, WIN, NS), 21)
+    ne = _load(pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cuda", ZDIM, NFFT, HOP, WIN, NS), 22)
+    ye = _load(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cuda", ZDIM, NFFT, HOP, WIN, NS, 2), 23)
+    assert ye.lstms[0].hidden_size == 6 * ZDIM and ye.lstms[0].hidden_size % 16 == 0
+    for m_ in (ce, ne):
+        for p_ in m_.parameters():
+            p_.requires_grad = False
+    clean, noise, e = _vae_inputs(par, rank, world, 8)
+    noisy = clean + noise
+    par.enable_sync_bn()
+    red = par.GradAllReduce(ye.parameters())
+    with torch.no_grad():
+        c = ce(clean, train=False, eps=(e[0], e[1]))
+        n = ne(noise, train=False, eps=(e[2], e[3]))
+    with torch.enable_grad():
+        s = ye(noisy, train=True, eps=(e[4], e[5], e[6], e[7]))
+        L_ = nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.5, ZDIM, NS, 2, 'original', 'False', [], 'both')
+        loss = L_.final_nsvae_loss(c[1], n[1], s[1], s[5], c[2], n[2], s[2], s[6], c[3], n[3], s[3], s[7],
+                                   s[0], s[4], c[4], n[4], s[8])[0]
+        loss.backward()
+    red.reduce()
+    assert all(p_.grad is None for p_ in ce.parameters())
+    return _collect(loss, ye, NS_KEYS, NS_BUFS)
+
+
+TP_KEYS = ("dense.linear_read.weight", "dense.linear_imag.bias", "decoders.0.transconv.tconv_re.weight",
+           "decoders.2.transconv.tconv_im.weight", "decoders.3.bn.gamma_ri", "decoders.4.bn.beta_i", "decoders.1.prelu.weight",
+           "decoders.5.transconv.tconv_re.weight")
+TP_BUFS = ("decoders.0.bn.Vri", "decoders.3.bn.running_mean_real", "decoders.5.bn.Vii")
+
+
+def _twophase_step(rank, world):
+    """BASELINE config 5 per rank (train_second_phase_decoder.py:376-433): frozen NSVAE encoder in eval mode, the decoder in
+    train mode with the encoder's real skips repeated num_samples times (pad='sig'), mask, SI-SNR, backward, averaging."""
+    pm = importlib.import_module("i-dccrn-vae_amd.model.pvae_module")
+    nl = importlib.import_module("i-dccrn-vae_amd.model.nsvae_loss")
+    par = importlib.import_module("i-dccrn-vae_amd.parallel")
+    np_ = O.net_params(True, 4)
+    ye = _load(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cuda", ZDIM, NFFT, HOP, WIN, NS, 2), 23)
+    de = _load(pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, "cuda", NS, ZDIM, NFFT, HOP, WIN, "mask", True, SKIP, False), 24)
+    for p_ in ye.parameters():
+        p_.requires_grad = False
+    clean, noise, e = _vae_inputs(par, rank, world, 4)
+    noisy = clean + noise
+    B, L = clean.shape
+    par.enable_sync_bn()
+    red = par.GradAllReduce(de.parameters())
+    with torch.enable_grad():
+        r = ye(noisy, train=False, eps=tuple(e))
+        rec, prd = de(r[11], r[0], r[8], r[9], r[10], train=True, pad='sig')
+        cb = clean.unsqueeze(1).repeat(1, NS, 1).view(B * NS, L)
+        sxc = ye.stft(clean).unsqueeze(1).repeat(1, NS, 1, 1, 1).view(B * NS, r[11].shape[1], r[11].shape[2], 2)
+        loss = nl.two_phase_loss([0.1, 0.1, 1], 1.0, ZDIM, 1).phase_2_loss(prd, sxc, cb, rec, None, None, None, None)[0]
+        loss.backward()
+    red.reduce()
+    return _collect(loss, de, TP_KEYS, TP_BUFS)
+
+
+STEPS = {"dccrn": (_train_step, KEYS, BUFS), "nsvae": (_nsvae_step, NS_KEYS, NS_BUFS), "twophase": (_twophase_step, TP_KEYS, TP_BUFS)}
+
+
+def _worker(rank, world, port, q, kind):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _train_step(rank, world))
+        q.put((rank,) + STEPS[kind][0](rank, world))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank_full_batch():
+@pytest.mark.parametrize("kind", ["dccrn", "nsvae", "twophase"])
+def test_two_ranks_equal_one_rank_full_batch(kind):
+    step, KEYS, BUFS = STEPS[kind]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
     out = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    full_loss, full_g, full_b, full_n = _train_step(0, 1)
+    full_loss, full_g, full_b, full_n = step(0, 1)
     # mean of the shard losses == loss of the full batch (equal shards)
     assert abs(0.5 * (out[0][1] + out[1][1]) - full_loss) < 1e-5 * max(1.0, abs(full_loss))
     for rank, _, grads, bufs, norms in out:

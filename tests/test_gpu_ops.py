@@ -365,8 +365,16 @@ def test_cooperative_recurrence_times_out_instead_of_hanging(ops, H, precision):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         os.environ.pop("IDV_COOP_FAULT")
+        # the time-out is surfaced through the C ABI, not only through NaNs: the sticky status says -3 (IDV_ECOOP) ...
+        lib = ops.L.lib()
+        assert lib.idv_coop_last_status(0) == -3
+        # ... and, if nobody collects it, the next cooperative entry refuses once with the same status
+        with pytest.raises(ops.L.IdvError, match="status -3"):
+            ops.clstm(xp, p0, p1, H)
+        assert lib.idv_coop_last_status(1) == 0
         again = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
         torch.cuda.synchronize()
+        assert lib.idv_coop_last_status(1) == 0
     finally:
         os.environ.pop("IDV_COOP_FAULT", None)
         ops.set_precision(keep)
