@@ -309,6 +309,10 @@ def kernel_name(cfg_id):
         return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
     if cfg_id == 1000001:
         return "void (anonymous namespace)::ctconv_c1_f32_kernel<false>(CgemmArgs, int)"
+    if 300000 <= cfg_id < 400000:       # idv_cconv_gauss_config digits 3 MODE WM WN FO_T JC_W
+        d = str(cfg_id)
+        return (f"void (anonymous namespace)::cgemm_gauss_kernel<{d[1]}, {d[2]}, {d[3]}, {d[4]}, {d[5]}, 2, false, true>"
+                "((anonymous namespace)::GaussArgs)")
     if cfg_id > 0:
         d = str(cfg_id)
         mode, t = (1 if len(d) == 7 else 0), d[-6:]
@@ -366,6 +370,12 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
         "per_kernel": {kernel_name(k): {"tflops": round(2 * v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3)}
                        for k, v in sorted(groups.items())},
     }
+    if 300000 <= dom < 400000:
+        # three real products per complex product (Gauss, cgemm_gauss.hip): `achieved` counts the reference's 4 real convolutions
+        r["executed"] = round(0.75 * ach, 3)
+        r["frac_executed"] = round(0.75 * ach / peak, 4)
+        r["peak_note"] = ("dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32); achieved counts ALGORITHMIC flops (the reference's 4 real "
+                          "convolutions per complex convolution, SURVEY 8(d)), the kernel executes 3 (Gauss): `executed` = 0.75 x achieved")
     if split:
         r["executed_bf16_tflops"] = round(3 * ach, 1)
         r["frac_executed"] = round(3 * ach / peak, 4)

@@ -56,7 +56,6 @@ class ConvBlockFn(torch.autograd.Function):
         x = _mk(xbuf, xg)
         skip = _mk(skipbuf, sg) if skipbuf is not None else None
         cin_used = x.C if zero_skip else None
-        wfrag, bias = conv.packed(None, cin_used)
         cout = conv.out_channel
         dev = xbuf.device
         # bf16x3 training mode: forward and data gradient on the split-bf16 MFMA kernels where the shape allows
@@ -64,6 +63,8 @@ class ConvBlockFn(torch.autograd.Function):
         wbf = None
         if ops.PRECISION == "bf16x3" and ops.bf16_supported(conv._transposed, x.C, skip.C if skip is not None else 0, 1, cout):
             wbf = conv.packed_bf16(None, cin_used)
+        gauss = conv.gauss_for(x.C, skip.C if skip is not None else 0, None, cin_used) if wbf is None else None
+        wfrag, bias = conv.packed(None, cin_used) if gauss is None else (None, None)
         if bn is not None:
             stats = torch.zeros(cout, 5, dtype=torch.float64, device=dev)
             if wbf is not None and ops.IMAGE_TRAIN and x.Jp == (skip.Jp if skip is not None else x.Jp):
@@ -73,7 +74,7 @@ class ConvBlockFn(torch.autograd.Function):
                                           skip=_image_of(skipbuf, skip) if skip is not None else None)
             else:
                 y = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, stats=stats,
-                                wfrag_bf16=wbf)
+                                wfrag_bf16=wbf, gauss=gauss)
             first = bool(bn.init_flag)
             moments, fold = ops.cbn_finalize(stats, float(y.B) * y.F * y.T, bn, first, bn.momentum)
             bn._stats_gen += 1
@@ -86,7 +87,7 @@ class ConvBlockFn(torch.autograd.Function):
                 z = ops.cbn_apply_to(y, fold, slope)
             ctx.save_for_backward(xbuf, skipbuf, w_re, w_im, y.buf, fold, moments, g_rr, g_ri, g_ii, slope)
         else:
-            z = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, wfrag_bf16=wbf)
+            z = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, wfrag_bf16=wbf, gauss=gauss)
             ctx.save_for_backward(xbuf, skipbuf, w_re, w_im, None, None, None, None, None, None, None)
         ctx.meta = meta
         ctx.zgeom = _geom(z)
@@ -119,18 +120,25 @@ class ConvBlockFn(torch.autograd.Function):
         # normalisation makes every channel of dy sum to zero over the batch (sum dy = Z^T sum du + A sum (y - mu) + N c with
         # sum (y - mu) = 0 and c = -Z^T sum du / N, cbn_bwd_finalize); what autograd returns there in the reference is
         # rounding noise far below the weight-decay term of its Adam step.  No pass over dy for it.
-        if bn is not None:
-            db_re = torch.zeros(cout, dtype=torch.float32, device=dzbuf.device)
-            db_im = torch.zeros_like(db_re)
-        else:
-            db_re, db_im = ops.cconv_bias_grad(dy)
+        # frozen layers (requires_grad False on the conv parameters, e.g. train_second_phase_decoder.py:145-149 unfreezes only
+        # part of the decoder) skip the weight-gradient contraction, the most expensive backward kernel of a block
+        need_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        need_b = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
+        db_re = db_im = dw_re = dw_im = None
+        if need_b:
+            if bn is not None:
+                db_re = torch.zeros(cout, dtype=torch.float32, device=dzbuf.device)
+                db_im = torch.zeros_like(db_re)
+            else:
+                db_re, db_im = ops.cconv_bias_grad(dy)
         cin_total = w_re.shape[0] if tr else w_re.shape[1]
-        used = x.C + (skip.C if skip is not None else 0)
-        mk = torch.zeros_like if used < cin_total else torch.empty_like
-        dw_re, dw_im = mk(w_re), mk(w_im)
-        ops.cconv_wgrad(x, 0, dy, cout, cin_total, tr, True, dw_re, dw_im)
-        if skip is not None:
-            ops.cconv_wgrad(skip, x.C, dy, cout, cin_total, tr, True, dw_re, dw_im)
+        if need_w:
+            used = x.C + (skip.C if skip is not None else 0)
+            mk = torch.zeros_like if used < cin_total else torch.empty_like
+            dw_re, dw_im = mk(w_re), mk(w_im)
+            ops.cconv_wgrad(x, 0, dy, cout, cin_total, tr, True, dw_re, dw_im)
+            if skip is not None:
+                ops.cconv_wgrad(skip, x.C, dy, cout, cin_total, tr, True, dw_re, dw_im)
         # data gradients: the adjoint operator with conjugate-transposed weights
         dx = dskip = None
         need_x, need_s = ctx.needs_input_grad[1], ctx.needs_input_grad[2] and skip is not None
@@ -163,6 +171,10 @@ def _dgrad(dy: Planar, w_re, w_im, cout_adj: int, cin_adj: int, fwd_transposed: 
             return ops.cconv2d_img(dy_img, w16, zb, cout_adj, transposed=adj_tr, causal=True, adjoint=True, want_planar=True,
                                    want_image=False)[0]
         return ops.cconv_dgrad(dy, None, zb, cout_adj, fwd_transposed, True, wfrag_bf16=w16)
+    if ops.PRECISION == "fp32" and ops.gauss_supported(cin_adj, 0, cout_adj):
+        # exact fp32 with three real products per complex product (csrc/cgemm_gauss.hip)
+        g3 = ops.pack_cconv_gauss(w_re, w_im, None, None, None, adjoint_of=(cout_adj, cin_adj, cin_adj, adj_tr))
+        return ops.cconv_dgrad(dy, None, None, cout_adj, fwd_transposed, True, gauss=g3)
     wf, bz = ops.pack_cconv_adjoint(w_re, w_im, cout_adj, cin_adj, cin_adj, adj_tr)
     return ops.cconv_dgrad(dy, wf, bz, cout_adj, fwd_transposed, True)
 
@@ -290,7 +302,7 @@ class LstmFn(torch.autograd.Function):
         work = torch.empty(int(nwork), dtype=torch.float32, device=xbuf.device)
         # bf16x3 training mode: the split-bf16 recurrences (H = 128 register-resident, H = 384 / 768 persistent cooperative)
         # also save the gates and cell states the fp32 BPTT kernels read; every other size keeps the exact-fp32 recurrence
-        flags = 4
+        flags = 4 if ops.LSTM_PERSISTENT else 4 | 8            # bit 3: per-step / one-CU kernels instead of the cooperative ones
         if ops.PRECISION == "bf16x3" and (H == 128 or (ops.LSTM_PERSISTENT and L.lib().idv_lstm_pers_supported(i(H), i(x.B)))):
             flags |= 1
         wih1_16 = None
@@ -312,6 +324,12 @@ class LstmFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dobuf):
         xbuf, work, *params = ctx.saved_tensors
+        # idv_lstm_bptt replaces the saved gate activations in `work` by gate gradients through raw pointers (torch's
+        # saved-tensor version check cannot see that): a second backward over the same graph would silently be wrong
+        if getattr(ctx, "_idv_consumed", False):
+            raise RuntimeError("ComplexLSTM backward ran twice over one forward (retain_graph=True / two losses sharing the "
+                               "LSTM): the saved gate buffer is consumed in place by the first pass; run forward again")
+        ctx._idv_consumed = True
         P = dict(zip(_LSTM_NAMES, params))
         mod = ctx.mod
         x = _mk(xbuf, ctx.geom)

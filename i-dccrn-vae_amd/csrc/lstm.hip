@@ -600,6 +600,12 @@ int launch_rec(const RecArgs& ra, float* cstate, int flags, hipStream_t st) {
         return idv_lstm_rec_pers(ra.g, ra.g_run_z, ra.g_run_s, ra.ldg, ra.whh, (ra.kimg && !ra.gsave) ? nullptr : ra.hout, ra.H, ra.B, ra.T,
                                  (void*)(cstate + 4LL * ra.B * ra.H), ra.kimg, ra.kimg_lo, ra.Tp, ra.Jp, ra.gsave, ra.csave, (void*)st);
     }
+    if (!(flags & 1) && !(flags & 8) && cstate && idv_lstm_pers_f32_supported(ra.H, ra.B)) {
+        // H = 384 / 768, exact fp32: one persistent cooperative launch per layer (lstm_pers_f32.hip) instead of T per-step
+        // launches; flags bit 3 keeps the per-step kernel
+        return idv_lstm_rec_pers_f32(ra.g, ra.g_run_z, ra.g_run_s, ra.ldg, ra.whh, ra.hout, ra.H, ra.B, ra.T,
+                                     (void*)(cstate + 4LL * ra.B * ra.H), ra.gsave, ra.csave, (void*)st);
+    }
     if (ra.H == 128 && (flags & 1)) {
         hipLaunchKernelGGL(lstm_rec_bf16_kernel, grid, dim3(256), 0, st, ra);
     } else if (ra.H == 128 && cstate && !(flags & 8) && idv_lstm_coop_f32_supported(ra.H, ra.B)) {
@@ -643,6 +649,10 @@ static long long hp_floats(int H, int B, int Jp) {
     }
     if (idv_lstm_coop_f32_supported(H, B)) {
         const long long m = (idv_lstm_coop_f32_work_bytes(H, B) + 3) / 4;
+        if (m > n) n = m;
+    }
+    if (idv_lstm_pers_f32_supported(H, B)) {
+        const long long m = (idv_lstm_pers_f32_work_bytes(H, B) + 3) / 4;
         if (m > n) n = m;
     }
     return (n + 63) / 64 * 64;

@@ -103,6 +103,7 @@ class _ComplexConvBase(nn.Module):
         self._cache = _PackCache()
         self._cache_bf16 = _PackCache()
         self._cache_c1 = _PackCache()
+        self._cache_gauss = _PackCache()
 
     @property
     def _re(self):
@@ -126,6 +127,18 @@ class _ComplexConvBase(nn.Module):
         return self._cache.get(tensors, cin_used, lambda: ops.pack_cconv(
             re.weight.detach(), im.weight.detach(), re.bias.detach(), im.bias.detach(), fold, cin_used, self._transposed))
 
+    def packed_gauss(self, fold: Optional[torch.Tensor], cin_used: Optional[int] = None):
+        """(wfrag3, epi, has_fold) of the three-product fp32 kernel (ops.pack_cconv_gauss); fold is applied by its epilogue."""
+        re, im = self._re, self._im
+        return self._cache_gauss.get((re.weight, im.weight, re.bias, im.bias, fold), cin_used, lambda: ops.pack_cconv_gauss(
+            re.weight.detach(), im.weight.detach(), re.bias.detach(), im.bias.detach(), fold, cin_used, self._transposed))
+
+    def gauss_for(self, c0: int, c1: int, fold, cin_used):
+        """fp32 mode: the Gauss operands if the three-product kernel serves this launch, else None (-> cgemm_kernel)."""
+        if ops.PRECISION != "fp32" or not ops.gauss_supported(c0, c1, self.out_channel):
+            return None
+        return self.packed_gauss(fold, cin_used)
+
     def packed_bf16(self, fold: Optional[torch.Tensor], cin_used: Optional[int] = None):
         re, im = self._re, self._im
         return self._cache_bf16.get((re.weight, im.weight, fold), cin_used, lambda: ops.pack_cconv_bf16(
@@ -148,10 +161,15 @@ class _ComplexConvBase(nn.Module):
         cin_used = x.C if zero_skip else None
         if not zero_skip and x.C + (skip.C if skip is not None else 0) != self.in_channel:
             raise RuntimeError(f"expected {self.in_channel} input channels, got {x.C} + {skip.C if skip is not None else 0}")
-        wfrag, bias = self.packed(fold, cin_used)
         wbf = None
         c1 = skip.C if skip is not None else 0
         any_img = isinstance(x, ops.Image) or isinstance(skip, ops.Image)
+        if ops.PRECISION == "fp32" and not any_img and want == "planar":
+            g3 = self.gauss_for(x.C, c1, fold, cin_used)
+            if g3 is not None:           # fp32: three real products per complex product (csrc/cgemm_gauss.hip)
+                return ops.cconv2d(x, None, None, self.out_channel, transposed=self._transposed, causal=self._causal,
+                                   slope=slope, skip=skip, skip_div=skip_div, stats=stats, gauss=g3)
+        wfrag, bias = self.packed(fold, cin_used)
         if any_img and want == "planar" and self._c1_path(x.C, c1, stats, skip_div):
             # single-output-channel block: image sources, planar result
             x = x if isinstance(x, ops.Image) else ops.to_image(x)

@@ -311,6 +311,22 @@ def _predict_outputs(module, out: Planar, stft_in: Planar, recon_type: str, x_di
     raise ValueError(f"recon_type {recon_type!r}")
 
 
+def _eval_builds_no_graph(what, *inputs):
+    """train=False runs the folded-BN eval kernels, which have no backward.  The reference would still build a graph
+    through an eval-mode module; silently cutting a gradient that something upstream needs would be wrong, so an input
+    that requires grad is refused instead (parameters of the module itself get no gradient from an eval-mode forward)."""
+    def walk(t):
+        if isinstance(t, torch.Tensor):
+            return t.requires_grad
+        if isinstance(t, (list, tuple)):
+            return any(walk(u) for u in t)
+        return False
+    if any(walk(t) for t in inputs):
+        raise NotImplementedError(
+            f"{what}: forward(train=False) under enabled grad with an input that requires grad -- the eval-mode (folded batch norm) "
+            "kernels have no backward, the gradient would be cut silently; call with train=True, or detach() the input")
+
+
 class DCCRN_(nn.Module):
     """Supervised DCCRN (DCCRN-CL when causal=True).  reference: model/pvae_module.py:200-255.
     forward(signal [B, L], train=True) -> (clean [B, hop*(T-1)], predict complex64 [B, F, T])."""
@@ -333,6 +349,7 @@ class DCCRN_(nn.Module):
         # CBN statistics and stays on one stream.
         if not train and torch.is_grad_enabled():
             # eval mode builds no graph: the folded-BN kernels have no backward (module docstring)
+            _eval_builds_no_graph(type(self).__name__, signal)
             with torch.no_grad():
                 return self.forward(signal, False)
         n = 1 if train else ops.stream_split(signal.shape[0])
@@ -446,6 +463,7 @@ class pvae_dccrn_encoder_skip_prepare(_VAEEncoderBase):
 
     def forward(self, x, train=True, eps=None):
         if not train and torch.is_grad_enabled():
+            _eval_builds_no_graph(type(self).__name__, x)
             with torch.no_grad():                                    # eval mode builds no graph
                 return self.forward(x, False, eps)
         lat, skiper, C, F, stft_x = self._encode(x, train)
@@ -468,6 +486,7 @@ class nsvae_pvae_dccrn_encoder_twophase(_VAEEncoderBase):
 
     def forward(self, x, train=True, eps=None):
         if not train and torch.is_grad_enabled():
+            _eval_builds_no_graph(type(self).__name__, x)
             with torch.no_grad():                                    # eval mode builds no graph
                 return self.forward(x, False, eps)
         lat, skiper, C, F, stft_x = self._encode(x, train)
@@ -500,6 +519,7 @@ class _VAEDecoderBase(nn.Module):
 
     def _decode(self, stft_x, z, skiper, C, F, train, pad):
         if not train and torch.is_grad_enabled():
+            _eval_builds_no_graph(type(self).__name__, z, skiper if pad != 'zero' else None)
             with torch.no_grad():                                    # eval mode builds no graph
                 return self._decode(stft_x, z, skiper, C, F, False, pad)
         zp = getattr(z, "_idv", None)

@@ -225,6 +225,37 @@ def pack_cconv(w_re, w_im, b_re, b_im, fold, cin_used: Optional[int] = None, tra
     return wfrag, bias
 
 
+def gauss_supported(c0: int, c1: int, cout: int) -> bool:
+    """fp32 mode: does the three-product (Gauss) contraction kernel serve this layer (csrc/cgemm_gauss.hip)?"""
+    return bool(L.lib().idv_cconv_gauss_supported(i(c0), i(c1), i(cout)))
+
+
+def pack_cconv_gauss(w_re, w_im, b_re, b_im, fold, cin_used: Optional[int] = None, transposed=False, *, adjoint_of=None):
+    """-> (wfrag3, epi, has_fold) for idv_cconv2d_gauss_fwd.  adjoint_of=(cout_adj, cin_total_adj, cin_used_adj, adj_transposed):
+    the data-gradient operator (conjugate-transposed weights, no bias), arguments describing the adjoint as pack_cconv_adjoint."""
+    if adjoint_of is not None:
+        cout, cin_total, cin_used, transposed = adjoint_of
+    else:
+        if transposed:
+            cin_total, cout = w_re.shape[0], w_re.shape[1]
+        else:
+            cout, cin_total = w_re.shape[0], w_re.shape[1]
+        cin_used = cin_total if cin_used is None else cin_used
+    lib = L.lib()
+    lib.idv_cconv_gauss_wfrag_floats.restype = L._L
+    wfrag = torch.empty(int(lib.idv_cconv_gauss_wfrag_floats(i(cout), i(cin_used))), dtype=torch.float32, device=w_re.device)
+    epi = torch.empty(int(lib.idv_cconv_gauss_epi_rows(i(cout))) * 8, dtype=torch.float32, device=w_re.device)
+    if adjoint_of is not None:
+        # adjoint of a conv [Cout][Cin] is a transposed conv whose [Cin'][Cout'] weight IS that tensor (Cin' = Cout), and vice
+        # versa: same memory, the other interpretation, W_i negated (idv_pack_cconv_adjoint does the same)
+        call("idv_pack_cconv_gauss", p(w_re), p(w_im), p(None), p(None), p(None), i(cout), i(cin_total), i(cin_used),
+             i(1 if transposed else 0), i(1), p(wfrag), p(epi), stream_ptr())
+        return wfrag, epi, 0
+    call("idv_pack_cconv_gauss", p(w_re.contiguous()), p(w_im.contiguous()), p(b_re.contiguous()), p(b_im.contiguous()), p(fold),
+         i(cout), i(cin_total), i(cin_used), i(1 if transposed else 0), i(0), p(wfrag), p(epi), stream_ptr())
+    return wfrag, epi, (1 if fold is not None else 0)
+
+
 def bf16_supported(transposed: bool, c0: int, c1: int, skip_div: int, cout: int) -> bool:
     return bool(L.lib().idv_cconv_bf16_supported(i(1 if transposed else 0), i(c0), i(c1), i(skip_div), i(cout)))
 
@@ -356,7 +387,7 @@ def concurrent(fns, device=None):
 
 def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True, slope=None, skip: Optional[Planar] = None,
             skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None,
-            wfrag_bf16: Optional[torch.Tensor] = None, image: str = "", adjoint_time: bool = False):
+            wfrag_bf16: Optional[torch.Tensor] = None, image: str = "", adjoint_time: bool = False, gauss=None):
     """(causal_)ComplexConv2d / (causal_)ComplexConvTranspose2d forward on planar activations.
     image="also" / "only": the exact-fp32 kernel additionally / only writes a split-bf16 image -> (Planar|None, Image)."""
     Fout = 2 * x.F - 1 if transposed else (x.F - 1) // 2 + 1
@@ -399,9 +430,17 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
             ev1.record()
             LAUNCH_LOG.append((cfg, macs, ev0, ev1))
         return out
-    call("idv_cconv2d_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
-         i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag), p(bias), p(slope), out.ptr(), p(stats),
-         i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+    if gauss is not None:
+        # fp32: three real products per complex product (csrc/cgemm_gauss.hip); gauss = (wfrag3, epi, has_fold)
+        if LAUNCH_LOG is not None:
+            cfg = L.lib().idv_cconv_gauss_config(i(1 if transposed else 0), i(cout), i(x.F))
+        call("idv_cconv2d_gauss_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
+             i(skip.Jp if skip is not None else 0), i(skip_div), p(gauss[0]), p(gauss[1]), i(gauss[2]), p(slope), out.ptr(),
+             p(stats), i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+    else:
+        call("idv_cconv2d_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
+             i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag), p(bias), p(slope), out.ptr(), p(stats),
+             i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
     if LAUNCH_LOG is not None:
         ev1.record()
         LAUNCH_LOG.append((cfg, macs, ev0, ev1))
@@ -768,7 +807,7 @@ def zero_bias(cout: int, device):
     return _ZBIAS[key]
 
 
-def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, causal: bool, wfrag_bf16=None) -> Planar:
+def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, causal: bool, wfrag_bf16=None, gauss=None) -> Planar:
     """Data gradient of a causal_complex_conv2d / causal_ComplexConvTranspose2d: the adjoint operator on idv_cconv2d_fwd
     (transposed conv reading (dy[t+1], dy[t]) / conv reading (dy[t], dy[t+1]); all T frames kept: column T+1 is the next
     utterance's zero guard column).  wfrag_bf16: run it on the split-bf16 kernel instead (bf16x3 training mode)."""
@@ -784,9 +823,16 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
         if wfrag_bf16 is not None:
             cfg = -(1000000 + L.lib().idv_cconv_bf16_config(i(1 if adj_transposed else 0), i(cout_adj), i(dy.F)))
         ev0.record()
-    call("idv_cconv2d_bf16x3_fwd" if wfrag_bf16 is not None else "idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1),
-         p(wfrag_bf16 if wfrag_bf16 is not None else wfrag), p(bias), p(None), out.ptr(), p(None),
-         i(1 if adj_transposed else 0), i(0), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(dy.T), stream_ptr())
+    if gauss is not None and wfrag_bf16 is None:
+        if LAUNCH_LOG is not None:
+            cfg = L.lib().idv_cconv_gauss_config(i(1 if adj_transposed else 0), i(cout_adj), i(dy.F))
+        call("idv_cconv2d_gauss_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(gauss[0]), p(gauss[1]), i(0), p(None),
+             out.ptr(), p(None), i(1 if adj_transposed else 0), i(0), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(dy.T),
+             stream_ptr())
+    else:
+        call("idv_cconv2d_bf16x3_fwd" if wfrag_bf16 is not None else "idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1),
+             p(wfrag_bf16 if wfrag_bf16 is not None else wfrag), p(bias), p(None), out.ptr(), p(None),
+             i(1 if adj_transposed else 0), i(0), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(dy.T), stream_ptr())
     if LAUNCH_LOG is not None:
         ev1.record()
         LAUNCH_LOG.append((cfg, macs, ev0, ev1))

@@ -97,6 +97,27 @@ int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, i
                     const float* bias, const float* prelu_slope, float* out, double* stats, int transposed,
                     int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
 
+/* idv_cconv2d_fwd with THREE real products per complex product (Gauss: t1 = Wr (xr + xi), t2 = (Wi - Wr) xr,
+ * t3 = (Wr + Wi) xi; re = t1 - t3, im = t1 + t2 -- cgemm_gauss.hip), exact fp32 MFMA: the same reference lines
+ * (model/complex_progress.py:16-22, :32-36, :244-250, :275-279), 25 % fewer multiplications than the reference's four real
+ * convolutions.  idv_cconv_gauss_supported(C0, C1, Cout): >= 2 complex input channels, > 1 output channel, and with a second
+ * source C0 even; callers use idv_cconv2d_fwd otherwise (the one-channel ends of the network).  idv_pack_cconv_gauss: weight
+ * layouts as idv_pack_cconv; wfrag: idv_cconv_gauss_wfrag_floats(Cout, Cin_used) floats; epi: idv_cconv_gauss_epi_rows(Cout)
+ * x 8 floats per output channel (Zrr, Zri, Zir, Zii, (Z b + s)_r, (Z b + s)_i, 0, 0) with b = (b_re - b_im, b_re + b_im) --
+ * eval-mode ComplexBatchNormal (fold, complex_progress.py:161-209) is a real 2x2 map, so it cannot be folded into the three
+ * weight planes and is applied by the epilogue when has_fold != 0 (then PReLU, pvae_module.py:58,82).  conj != 0 packs the
+ * adjoint (data-gradient) operator: W_i negated, the caller passes the swapped channel roles as for idv_pack_cconv_adjoint.
+ * idv_cconv_gauss_config: the kernel instantiation as digits 3 MODE WM WN FO_T JC_W (profiles). */
+int idv_cconv_gauss_supported(int C0, int C1, int Cout);
+long long idv_cconv_gauss_wfrag_floats(int Cout, int cin_used);
+int idv_cconv_gauss_epi_rows(int Cout);
+int idv_cconv_gauss_config(int transposed, int Cout, int Fin);
+int idv_pack_cconv_gauss(const float* w_re, const float* w_im, const float* b_re, const float* b_im, const float* fold, int Cout,
+                         int Cin_total, int Cin_used, int transposed, int conj, float* wfrag, float* epi, void* stream);
+int idv_cconv2d_gauss_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const float* wfrag,
+                          const float* epi, int has_fold, const float* prelu_slope, float* out, double* stats, int transposed,
+                          int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
+
 /* Split-precision variant of idv_cconv2d_fwd (same reference lines): operands split into two bf16 (x = hi + lo),
  * w*x ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi accumulated in fp32 on the bf16 MFMA (relative error ~2^-16 per
  * product; waveform parity vs the fp32 path ~1e-5, north_star tolerance 1e-3).  Needs C0 % 8 == 0, C1 % 8 == 0,
@@ -231,6 +252,14 @@ int idv_lstm_proj1_bf16x3(const void* himg, long long lo_off_slots, const void* 
 int idv_lstm_coop_f32_supported(int H, int B);
 long long idv_lstm_coop_f32_work_bytes(int H, int B);
 int idv_lstm_rec_coop_f32(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh_frag, float* hout, int H,
+                          int B, int T, void* work, float* gsave, float* csave, void* stream);
+/* The same persistent cooperative recurrence in EXACT fp32 (lstm_pers_f32.hip; reference model/complex_progress.py:50-74 at the
+ * hidden sizes of model/pvae_module.py:1819, :2160-2163): W_hh slices as fp32 in registers, v_mfma_f32_16x16x4_f32, h exchanged
+ * as fp32 16-byte sc1 granules.  idv_clstm_fwd uses it in fp32 mode for H = 384 / 768 when idv_lstm_pers_f32_supported
+ * (IDV_LSTM_PERS_F32=0 or flags bit 3 keep the per-step kernel).  Arguments as idv_lstm_rec_coop_f32. */
+int idv_lstm_pers_f32_supported(int H, int B);
+long long idv_lstm_pers_f32_work_bytes(int H, int B);
+int idv_lstm_rec_pers_f32(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh_frag, float* hout, int H,
                           int B, int T, void* work, float* gsave, float* csave, void* stream);
 /* diagnostic (not part of the drop-in boundary): while a device buffer of 256 x 8 counters is registered, idv_lstm_rec_pers runs
  * an instrumented twin in which every workgroup accumulates core-clock cycles per phase (spin, -, barrier, loads + MFMA,

@@ -58,7 +58,7 @@ def _train_step(rank, world):
             {k: float(v.grad.double().norm()) for k, v in params.items() if v.grad is not None})
 
 
-ZDIM, NS, BG, LG = 8, 2, 4, 1600          # zdim 8 -> LSTM hidden 24 (CVAE / NVAE encoders) and 48 (noisy encoder, latent_num 2)
+ZDIM, NS, BG, LG = 16, 2, 4, 1600         # zdim 16 -> LSTM hidden 48 (CVAE / NVAE encoders) and 96 (noisy encoder, latent_num 2)
 
 
 def _load(module, seed):
@@ -163,7 +163,12 @@ def _worker(rank, world, port, q, kind):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + STEPS[kind][0](rank, world))
+        try:
+            q.put((rank,) + STEPS[kind][0](rank, world))
+        except BaseException:            # the parent must not sit in q.get() until its time-out: hand the failure over
+            import traceback
+            q.put((rank, "error", traceback.format_exc()))
+            raise
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -178,7 +183,17 @@ def test_two_ranks_equal_one_rank_full_batch(kind):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
-    out = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    out = []
+    for _ in procs:
+        r = q.get(timeout=300)
+        if len(r) == 3 and r[1] == "error":
+            for p in procs:
+                p.join(timeout=30)
+                if p.is_alive():
+                    p.terminate()
+            pytest.fail(f"rank {r[0]} failed:\n{r[2]}")
+        out.append(r)
+    out.sort(key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

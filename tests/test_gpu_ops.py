@@ -24,7 +24,7 @@ def T_(a):
 
 
 def _conv_case(ops, causal, transposed, cin, cout, F, T, B, seed, Tp_extra=1, fold=False, slope=None, skip_c=0,
-               skip_div=1):
+               skip_div=1, gauss=False):
     g = torch.Generator().manual_seed(seed)
     dev = "cuda"
     cin_tot = cin + skip_c
@@ -57,8 +57,15 @@ def _conv_case(ops, causal, transposed, cin, cout, F, T, B, seed, Tp_extra=1, fo
     Tp = max(T, want.shape[3]) + Tp_extra
     xp = ops.Planar.from_tensor5(x.to(dev), Tp)
     skp = ops.Planar.from_tensor5(sk.to(dev), Tp) if sk is not None else None
-    wfrag, bias = ops.pack_cconv(wr.to(dev), wi.to(dev), br.to(dev), bi.to(dev), fold_t, transposed=transposed)
-    y = ops.cconv2d(xp, wfrag, bias, cout, transposed=transposed, causal=causal, slope=slope_t, skip=skp, skip_div=skip_div)
+    if gauss:
+        # the three-product kernel (csrc/cgemm_gauss.hip): BN fold applied in its epilogue
+        assert ops.gauss_supported(cin, skip_c, cout)
+        g3 = ops.pack_cconv_gauss(wr.to(dev), wi.to(dev), br.to(dev), bi.to(dev), fold_t, transposed=transposed)
+        y = ops.cconv2d(xp, None, None, cout, transposed=transposed, causal=causal, slope=slope_t, skip=skp, skip_div=skip_div,
+                        gauss=g3)
+    else:
+        wfrag, bias = ops.pack_cconv(wr.to(dev), wi.to(dev), br.to(dev), bi.to(dev), fold_t, transposed=transposed)
+        y = ops.cconv2d(xp, wfrag, bias, cout, transposed=transposed, causal=causal, slope=slope_t, skip=skp, skip_div=skip_div)
     torch.cuda.synchronize()
     got = y.tensor5().cpu()
     assert got.shape == want.shape
@@ -78,6 +85,56 @@ def _conv_case(ops, causal, transposed, cin, cout, F, T, B, seed, Tp_extra=1, fo
 ])
 def test_cconv_plain(ops, causal, transposed, cin, cout, F, T, B):
     _conv_case(ops, causal, transposed, cin, cout, F, T, B, seed=1)
+
+
+@pytest.mark.parametrize("causal,transposed,cin,cout,F,T,B,skip_c,skip_div,fold,slope", [
+    (True, False, 32, 64, 129, 70, 2, 0, 1, False, None),      # conv, 5 output rows per tile, two co tiles per workgroup
+    (True, False, 8, 40, 65, 33, 2, 0, 1, True, 0.2),          # conv, 3 rows per tile, ragged second co tile, fold + PReLU
+    (True, False, 6, 16, 33, 40, 3, 0, 1, False, None),        # conv, 1 row x 4 column tiles, one co tile
+    (True, False, 3, 8, 9, 21, 2, 0, 1, False, 0.1),           # odd channel count: ragged last K chunk
+    (False, False, 4, 8, 17, 9, 2, 0, 1, False, None),         # non-causal taps (x[t], x[t+1])
+    (True, False, 2, 16, 5, 700, 1, 0, 1, False, None),        # many column tiles
+    (True, True, 64, 64, 9, 70, 2, 0, 1, False, None),         # transposed conv, two co tiles
+    (True, True, 6, 4, 9, 9, 2, 0, 1, True, 0.3),
+    (False, True, 6, 4, 9, 9, 2, 0, 1, False, None),
+    (True, True, 16, 16, 5, 130, 5, 0, 1, False, None),
+    (True, True, 8, 4, 9, 30, 2, 8, 1, False, None),           # skip concat
+    (True, True, 8, 4, 9, 30, 6, 8, 3, True, 0.25),            # repeated skips (num_samples = 3): scalar staging path
+    (True, True, 8, 36, 17, 30, 4, 5, 2, False, None),         # odd skip channel count + repeated skips
+    (True, True, 32, 32, 33, 645, 2, 32, 1, False, 0.25),      # utterance-length columns, Tp = 646
+])
+def test_cconv_gauss(ops, causal, transposed, cin, cout, F, T, B, skip_c, skip_div, fold, slope):
+    """The fp32 three-product (Gauss) contraction against the oracle's four real convolutions, every tile shape."""
+    _conv_case(ops, causal, transposed, cin, cout, F, T, B, seed=21, fold=fold, slope=slope, skip_c=skip_c, skip_div=skip_div,
+               gauss=True)
+
+
+def test_cconv_gauss_stats_and_adjoint(ops):
+    """Train-mode moment sums of the three-product kernel = those of cgemm_kernel, and its adjoint (data gradient) form =
+    the adjoint on cgemm_kernel, for a conv and a transposed conv."""
+    g = torch.Generator().manual_seed(5)
+    dev = "cuda"
+    for transposed, cin, cout, F in ((False, 8, 40, 33), (True, 40, 8, 9)):
+        x = torch.randn(3, cin, F, 37, 2, generator=g)
+        shape = (cin, cout, 5, 2) if transposed else (cout, cin, 5, 2)
+        wr, wi = (torch.randn(shape, generator=g) * 0.2).to(dev), (torch.randn(shape, generator=g) * 0.2).to(dev)
+        br, bi = torch.randn(cout, generator=g).to(dev), torch.randn(cout, generator=g).to(dev)
+        xp = ops.Planar.from_tensor5(x.to(dev), 38)
+        wfrag, bias = ops.pack_cconv(wr, wi, br, bi, None, transposed=transposed)
+        g3 = ops.pack_cconv_gauss(wr, wi, br, bi, None, transposed=transposed)
+        st0 = torch.zeros(cout, 5, dtype=torch.float64, device=dev)
+        st1 = torch.zeros_like(st0)
+        y0 = ops.cconv2d(xp, wfrag, bias, cout, transposed=transposed, stats=st0)
+        y1 = ops.cconv2d(xp, None, None, cout, transposed=transposed, stats=st1, gauss=g3)
+        assert relerr(y1.tensor5().cpu(), y0.tensor5().cpu()) < 1e-5
+        assert relerr(st1.cpu(), st0.cpu()) < 1e-5
+        # adjoint: dy has the OUTPUT geometry; conjugate-transposed weights, reversed time taps
+        dy = ops.Planar.from_tensor5(torch.randn(3, cout, y0.F, 37, 2, generator=g).to(dev), 38)
+        wf, bz = ops.pack_cconv_adjoint(wr, wi, cin, cout, cout, not transposed)
+        ga = ops.pack_cconv_gauss(wr, wi, None, None, None, adjoint_of=(cin, cout, cout, not transposed))
+        d0 = ops.cconv_dgrad(dy, wf, bz, cin, transposed, True)
+        d1 = ops.cconv_dgrad(dy, None, None, cin, transposed, True, gauss=ga)
+        assert relerr(d1.tensor5().cpu(), d0.tensor5().cpu()) < 1e-5
 
 
 def test_cconv_fold_prelu(ops):
@@ -264,6 +321,42 @@ def test_clstm_vae_sizes(ops, precision, H, I, T, B):
     assert float(out.planes()[..., 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("H,B,T", [(384, 5, 60), (768, 32, 48), (384, 40, 30), (768, 33, 25), (768, 64, 20), (384, 64, 33)])
+def test_clstm_persistent_f32_matches_per_step(ops, H, B, T):
+    """The exact-fp32 persistent cooperative recurrence (lstm_pers_f32.hip) against the per-step fp32 kernels it replaces:
+    1, 2 and 4 row tiles per workgroup, several batch chunks, a ragged last tile; same fp32 products in another summation
+    order -> 2e-6; bit-repeatable."""
+    g = torch.Generator().manual_seed(H + B + 1)
+    I = 64
+    x = torch.randn(T, B, I, 2, generator=g) * 0.5
+    names = [f"lstm_{s}.{w}_l{l}" for s in ("re", "im") for l in (0, 1) for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    sd = {}
+    for n in names:
+        l = int(n[-1])
+        shape = (4 * H, I if l == 0 else H) if "weight_ih" in n else ((4 * H, H) if "weight_hh" in n else (4 * H,))
+        sd[n] = O.synth_tensor(n, shape, 93) * (2.0 if "weight" in n else 1.0)
+    xp = ops.Planar.from_tensor5(x.permute(1, 2, 0, 3).unsqueeze(2).cuda())
+    get = lambda n: sd[n].cuda()
+    keep = (ops.PRECISION, ops.LSTM_PERSISTENT)
+    try:
+        ops.set_precision("fp32")
+        p0, p1 = ops.pack_lstm(get, H, I, 0, "cuda"), ops.pack_lstm(get, H, H, 1, "cuda")
+        ops.LSTM_PERSISTENT = False
+        ref = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
+        ops.LSTM_PERSISTENT = True
+        assert amd_lib().idv_lstm_pers_f32_supported(H, B)
+        got = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
+        got2 = ops.clstm(xp, p0, p1, H).channel_slice(0, H)
+        torch.cuda.synchronize()
+        assert amd_lib().idv_coop_last_status(1) == 0
+    finally:
+        ops.set_precision(keep[0])
+        ops.LSTM_PERSISTENT = keep[1]
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, got2)
+    assert relerr(got.cpu(), ref.cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("H,B,T", [(384, 5, 60), (768, 32, 48), (384, 40, 30), (768, 33, 25)])
 def test_clstm_persistent_matches_per_step(ops, H, B, T):
     """The persistent cooperative recurrence (lstm_pers.hip: W_hh slices resident in registers, per-step arrive counter)
@@ -334,7 +427,7 @@ def test_clstm_coop_f32_matches_one_cu(ops, B, T):
     assert relerr(got.cpu(), ref.cpu()) < 1e-6
 
 
-@pytest.mark.parametrize("H,precision", [(128, "fp32"), (384, "bf16x3")])
+@pytest.mark.parametrize("H,precision", [(128, "fp32"), (384, "bf16x3"), (384, "fp32")])
 def test_cooperative_recurrence_times_out_instead_of_hanging(ops, H, precision):
     """Safety net of the cooperative recurrences (lstm_coop_f32.hip, lstm_pers.hip): with one workgroup withheld
     (IDV_COOP_FAULT=1 makes workgroup (0, 0, 0) return before its first arrive) every spin runs into its bound, the abort
