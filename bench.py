@@ -19,7 +19,8 @@ N = 1 only).  The headline is measured at the reference's precision (`dtype` "f3
 split-bf16 mode is attached as the clearly labelled secondary record `alt` (same workload, `dtype` "bf16x3"), together with
 a two-stream run of it whose output is compared bit for bit with the one-stream output (`two_stream_bit_exact`).
 
-Other workloads (--workload): cvae_elbo | nsvae_kl | twophase (BASELINE.json configs 2, 3, 5: forward + loss) and the
+Other workloads (--workload): enhance | enhance_complex_mask (the evaluation script's inference, 10 latent samples per
+utterance), cvae_elbo | nsvae_kl | twophase (BASELINE.json configs 2, 3, 5: forward + loss) and the
 TRAIN steps forward + loss + backward + Adam, as the reference's trainers run them: dccrn_cl_train
 (supervised_dccrn/train.py:233-243), cvae_train (pretrained_vaes/train.py:281-301), nsvae_train (train_nsvae.py:487-574,
 config 4) and twophase_train (train_second_phase_decoder.py:376-433, config 5).  With N > 1 the train steps shard the
@@ -122,6 +123,26 @@ def build_workload(name, B, device, rank):
             return loss.phase_2_loss(pred, s[11], clean, recon, None, None, None, None)[0]
         return step, B, {"workload": "two-phase decoder fine-tune forward: frozen NSVAE encoder + decoder(mask, pad='sig') + SI-SNR",
                          "batch_per_gpu": B}
+    if name in ("enhance", "enhance_complex_mask"):
+        # enhancement inference as the evaluation script runs it (test_se_cvaefinetune.py:251-311, num_samples = 10 in
+        # test_se_cvaefinetune.sh:8), batched: noisy encoder (eval) -> decoder(s) on 10 latent draws per utterance -> mean over
+        # the samples (latent_to_use 1) or the two-decoder complex-mask estimator (latent_to_use 2)
+        inf = importlib.import_module("i-dccrn-vae_amd.inference")
+        ns, zdim = 10, 128
+        se = synth_state(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, device, zdim, NFFT, HOP, WIN, ns, 2), 56).to(device)
+        dec = synth_state(pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, device, ns, zdim, NFFT, HOP, WIN, "mask", True, SKIP, False), 57).to(device)
+        if name == "enhance":
+            def step():
+                return inf.compute_sisdr(inf.enhance_vae(se, dec, noisy), clean).mean()
+            what = "enhancement inference: noisy encoder + fine-tuned decoder on 10 latent samples, mean over samples, SI-SDR"
+        else:
+            dn = synth_state(pm.nsvae_pvae_dccrn_decoder_twophase(np_, True, device, ns, zdim, NFFT, HOP, WIN, "mask", True, SKIP, False), 58).to(device)
+
+            def step():
+                return inf.compute_sisdr(inf.enhance_vae_two_latents(se, dec, dn, noisy, "complex_mask", 2), clean).mean()
+            what = ("enhancement inference, latent_to_use 2: noisy encoder + speech and noise decoders on 10 latent samples each, "
+                    "complex-mask estimator, ISTFT, SI-SDR")
+        return step, B, {"workload": what, "batch_per_gpu": B, "num_samples": ns}
     par = importlib.import_module("i-dccrn-vae_amd.parallel")
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -450,7 +471,7 @@ def main():
     global STREAM
     STREAM = args.stream
     if args.batch is None:
-        args.batch = 32 if train else DEFAULT_BATCH
+        args.batch = 32 if train else (16 if args.workload.startswith("enhance") else DEFAULT_BATCH)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher.  It never touches the GPU (no torch import,

@@ -88,6 +88,63 @@ __global__ void mask_apply_kernel(const float* __restrict__ mask, const float* _
     }
 }
 
+// Enhancement estimators of the two-latent evaluation path (reference i_dccrn_vae/nsvae_dccrn/test_se_cvaefinetune.py:
+// real_and_imag_mask :85-101, complex_mask :104-116, phase_sensitive_mask :119-135): S = mean over the ns sampled speech
+// spectra, N = mean over the ns sampled noise spectra, X = the noisy spectrum; mode 0: (Sr^2 / (Sr^2 + Nr^2 + eps)) Xr and the
+// same for the imaginary parts; mode 1: S / (S + N + eps) * X (complex); mode 2: |S| / (|S| + |N| + eps) * cos(angle S -
+// angle X) * |X| * exp(j angle S) = S * Re(S conj X) / (|S| (|S| + |N| + eps)) (0 where S = 0; where X = 0 both forms are 0).
+// speech / noise: interleaved complex [B*ns][F][T][2]; X: strided [B][F][T][2]; out: planar [2][F][Jp] (guard columns zeroed
+// by the caller), out_c (optional): interleaved complex [B][F][T][2].
+__global__ void outtype_kernel(const float* __restrict__ speech, const float* __restrict__ noise, const float* __restrict__ X,
+                               long long sb, long long sf, long long st_, long long sr, int mode, int ns, int B, int F, int T,
+                               int Tp, int Jp, float* __restrict__ out, float* __restrict__ out_c) {
+    const long long n = (long long)B * F * T;
+    const float eps = 1e-10f;
+    const float inv = 1.0f / (float)ns;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % T);
+        const int f = (int)((idx / T) % F);
+        const int b = (int)(idx / ((long long)T * F));
+        float s_r = 0.f, s_i = 0.f, n_r = 0.f, n_i = 0.f;
+        for (int k = 0; k < ns; ++k) {
+            const size_t o = ((((size_t)b * ns + k) * F + f) * T + t) * 2;
+            s_r += speech[o]; s_i += speech[o + 1];
+            n_r += noise[o]; n_i += noise[o + 1];
+        }
+        s_r *= inv; s_i *= inv; n_r *= inv; n_i *= inv;
+        const float* xp = X + b * sb + f * sf + t * st_;
+        const float xr = xp[0], xi = xp[sr];
+        float er, ei;
+        if (mode == 0) {
+            er = s_r * s_r / (s_r * s_r + n_r * n_r + eps) * xr;
+            ei = s_i * s_i / (s_i * s_i + n_i * n_i + eps) * xi;
+        } else if (mode == 1) {
+            const float dr = s_r + n_r + eps, di = s_i + n_i;          // complex + real eps
+            const float dd = dr * dr + di * di;
+            float mr = 0.f, mi = 0.f;
+            if (dd > 0.f) {
+                mr = (s_r * dr + s_i * di) / dd;
+                mi = (s_i * dr - s_r * di) / dd;
+            }
+            er = mr * xr - mi * xi;
+            ei = mr * xi + mi * xr;
+        } else {
+            const float sm = sqrtf(s_r * s_r + s_i * s_i), nm = sqrtf(n_r * n_r + n_i * n_i);
+            float g = 0.f;
+            if (sm > 0.f) g = (s_r * xr + s_i * xi) / (sm * (sm + nm + eps));
+            er = g * s_r;
+            ei = g * s_i;
+        }
+        const size_t j = (size_t)f * Jp + (size_t)b * Tp + t + 1;
+        out[j] = er;
+        out[(size_t)F * Jp + j] = ei;
+        if (out_c) {
+            out_c[idx * 2] = er;
+            out_c[idx * 2 + 1] = ei;
+        }
+    }
+}
+
 __global__ void planar_to_complex_kernel(const float* __restrict__ act, float* __restrict__ out_c, int F, int B, int T,
                                          int Tp, int Jp) {
     const long long n = (long long)B * F * T;
@@ -321,6 +378,23 @@ extern "C" int idv_datadenorm(const float* P, const float* mean, const float* st
     if (hipMemsetAsync(out, 0, sizeof(float) * 2 * (size_t)F * Jp, st) != hipSuccess) return IDV_ELAUNCH;
     hipLaunchKernelGGL(datadenorm_kernel, dim3(grid_for((long long)B * F * T)), dim3(256), 0, st, P, mean, stdv, F, B, T, Tp, Jp,
                        out, out_c);
+    return idv_launch_status();
+}
+
+// Two-latent enhancement estimators (test_se_cvaefinetune.py:85-135, used at :283-305): mode 0 real_imag_mask, 1 complex_mask,
+// 2 phase_mask.  speech_c / noise_c: the decoders' `predict` outputs, interleaved complex [B*ns][F][T][2]; X: the noisy STFT with
+// element strides (sb, sf, st, sr) for [b][f][t][re/im]; out: planar [2][F][Jp] spectrum for idv_pw_gemm + idv_istft_ola, out_c
+// (may be NULL): interleaved complex [B][F][T][2].
+extern "C" int idv_outtype_estimate(const float* speech_c, const float* noise_c, const float* X, long long sb, long long sf,
+                                    long long st_, long long sr, int mode, int ns, int B, int F, int T, int Tp, int Jp, float* out,
+                                    float* out_c, void* stream) {
+    if (!speech_c || !noise_c || !X || !out || mode < 0 || mode > 2 || ns < 1 || B <= 0 || F <= 0 || T <= 0 || Tp < T + 1 ||
+        Jp < B * Tp)
+        return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * 2 * (size_t)F * Jp, st) != hipSuccess) return IDV_ELAUNCH;
+    hipLaunchKernelGGL(outtype_kernel, dim3(grid_for((long long)B * F * T)), dim3(256), 0, st, speech_c, noise_c, X, sb, sf, st_, sr,
+                       mode, ns, B, F, T, Tp, Jp, out, out_c);
     return idv_launch_status();
 }
 

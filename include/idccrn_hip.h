@@ -219,6 +219,16 @@ int idv_mask_apply(const float* mask, const float* X, int x_div, int JpX, float*
 int idv_datanorm(const float* X, const float* mean, const float* stdv, int F, int B, int T, int Tp, int Jp, float* out, void* stream);
 int idv_datadenorm(const float* P, const float* mean, const float* stdv, int F, int B, int T, int Tp, int Jp, float* out,
                    float* out_c, void* stream);
+/* Two-latent enhancement estimators of the evaluation script (i_dccrn_vae/nsvae_dccrn/test_se_cvaefinetune.py:
+ * real_and_imag_mask :85-101, complex_mask :104-116, phase_sensitive_mask :119-135, applied at :283-305): S / N = mean over the
+ * ns sampled speech / noise spectra of an utterance, X = its noisy spectrum.  mode 0: per-part Wiener-like masks
+ * (Sr^2 / (Sr^2 + Nr^2 + 1e-10)) Xr, same for the imaginary part; 1: S / (S + N + 1e-10) * X; 2: |S| / (|S| + |N| + 1e-10) *
+ * cos(angle S - angle X) * |X| * exp(j angle S).  speech_c / noise_c: interleaved complex [B*ns][F][T][2] (the decoders'
+ * `predict`); X: [B][F][T][2] with element strides (sb, sf, st, sr); out: planar [2][F][Jp] (feeds the ISTFT), out_c or NULL:
+ * interleaved complex [B][F][T][2]. */
+int idv_outtype_estimate(const float* speech_c, const float* noise_c, const float* X, long long sb, long long sf, long long st,
+                         long long sr, int mode, int ns, int B, int F, int T, int Tp, int Jp, float* out, float* out_c,
+                         void* stream);
 /* planar [2][F][Jp] -> interleaved [B][F][T][2] (recon_type 'real_imag', pvae_module.py:245-253). */
 int idv_planar_to_complex(const float* act, float* out_c, int F, int B, int T, int Tp, int Jp, void* stream);
 

@@ -392,6 +392,50 @@ def apply_mask(mask: Tensor, stft_ri: Tensor) -> Tensor:
 # --------------------------------------------------------------------------- #
 # network tables (model/net_config.py, model/causal_netconfig.py)             #
 # --------------------------------------------------------------------------- #
+# --------------------------------------------------------------------------- #
+# Evaluation-path estimators.  The evaluation script itself is not importable here (librosa / soundfile /
+# pesq at module level); tests/golden/make_golden.py `evalpath` extracts exactly these pure-torch / pure-numpy function
+# definitions from the reference file's syntax tree, runs them, and pins the restatements below (op_outtype.npz, op_sisdr.npz).
+def outtype_real_imag_mask(noise_c: Tensor, speech_c: Tensor, noisy_ri: Tensor) -> Tensor:
+    """i_dccrn_vae/nsvae_dccrn/test_se_cvaefinetune.py:85-101.  noise_c / speech_c: complex [ns, F, T]; noisy_ri [1, F, T, 2]."""
+    n = torch.view_as_real(noise_c).mean(dim=0)
+    sp = torch.view_as_real(speech_c).mean(dim=0)
+    x = noisy_ri.mean(dim=0)
+    mr = sp[..., 0] ** 2 / (sp[..., 0] ** 2 + n[..., 0] ** 2 + 1e-10)
+    mi = sp[..., 1] ** 2 / (sp[..., 1] ** 2 + n[..., 1] ** 2 + 1e-10)
+    return torch.complex(mr * x[..., 0], mi * x[..., 1])
+
+
+def outtype_complex_mask(noise_c: Tensor, speech_c: Tensor, noisy_ri: Tensor) -> Tensor:
+    """test_se_cvaefinetune.py:104-116 (the eps is added to the complex denominator as a real number)."""
+    x = torch.complex(noisy_ri[..., 0], noisy_ri[..., 1]).squeeze(0)
+    n, sp = noise_c.mean(dim=0), speech_c.mean(dim=0)
+    return sp / (sp + n + 1e-10) * x
+
+
+def outtype_phase_sensitive_mask(noise_c: Tensor, speech_c: Tensor, noisy_ri: Tensor) -> Tensor:
+    """test_se_cvaefinetune.py:119-135: |S| / (|S| + |N| + eps) * cos(angle S - angle X) * |X| * exp(j angle S)."""
+    sp = speech_c.mean(dim=0)
+    n = noise_c.mean(dim=0)
+    x = torch.complex(noisy_ri[..., 0], noisy_ri[..., 1]).squeeze(0)
+    sph, smag, nmag = torch.angle(sp), torch.abs(sp), torch.abs(n)
+    mask = smag / (smag + nmag + 1e-10) * torch.cos(sph - torch.angle(x))
+    return mask * torch.abs(x) * torch.exp(1j * sph)
+
+
+def sisdr_np(x_est, x_ref):
+    """utils/eval_metrics.py:49-64 (numpy, one estimate / one reference; eps = machine epsilon of the estimate's dtype)."""
+    import numpy as np
+    eps = np.finfo(x_est.dtype).eps
+    ref = x_ref.reshape(x_ref.size, 1)
+    est = x_est.reshape(x_est.size, 1)
+    rss = np.dot(ref.T, ref)
+    a = (eps + np.dot(ref.T, est)) / (rss + eps)
+    e_true = a * ref
+    e_res = est - e_true
+    return 10 * np.log10((eps + (e_true ** 2).sum()) / (eps + (e_res ** 2).sum()))
+
+
 def net_params(causal: bool, base: int = 32, zdim_dense: int = 128) -> dict:
     """Shape table of model/causal_netconfig.py:5-103 / model/net_config.py:5-103
     (they differ only in the encoder time padding: 1 causal, 0 otherwise).  ``base``

@@ -612,8 +612,54 @@ def gen_checkpoint():
     print("wrote", folder, sum(os.path.getsize(os.path.join(folder, f)) for f in os.listdir(folder)) // 1024, "KiB")
 
 
+def _extract_functions(path, names):
+    """The named top-level function definitions of a reference file that cannot be imported here (its module-level imports
+    need librosa / soundfile / pesq), compiled from the file's own syntax tree and run as they stand: no stand-in modules,
+    nothing of the reference is written anywhere."""
+    import ast
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in picked) == sorted(names), [n.name for n in picked]
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def gen_evalpath():
+    """the three `outtype` estimators of the evaluation script and its SI-SDR metric, from the reference's own
+    function bodies (test_se_cvaefinetune.py:85-135, utils/eval_metrics.py:49-64)."""
+    print("== evaluation-path estimators")
+    import contextlib
+    import io
+    rim, cm, psm = _extract_functions(os.path.join(REF, "i_dccrn_vae", "nsvae_dccrn", "test_se_cvaefinetune.py"),
+                                      ["real_and_imag_mask", "complex_mask", "phase_sensitive_mask"])
+    (sisdr,) = _extract_functions(os.path.join(REF, "utils", "eval_metrics.py"), ["compute_sisdr"])
+    ns_, F, T = 3, 17, 23
+    speech = torch.complex(rnd(401, ns_, F, T), rnd(402, ns_, F, T))
+    noise = torch.complex(rnd(403, ns_, F, T, scale=0.7), rnd(404, ns_, F, T, scale=0.7))
+    noisy = rnd(405, 1, F, T, 2)
+    out = {}
+    for name, ref_fn, ora in (("real_imag_mask", rim, O.outtype_real_imag_mask), ("complex_mask", cm, O.outtype_complex_mask),
+                              ("phase_mask", psm, O.outtype_phase_sensitive_mask)):
+        with contextlib.redirect_stdout(io.StringIO()):          # complex_mask prints a debug line
+            want = ref_fn(noise.clone(), speech.clone(), noisy.clone())
+        got = ora(noise, speech, noisy)
+        check("outtype " + name, torch.view_as_real(got), torch.view_as_real(want), 1e-6)
+        out[name] = torch.view_as_real(want)
+    save("op_outtype", speech=torch.view_as_real(speech), noise=torch.view_as_real(noise), noisy=noisy, **out)
+    est = rnd(406, 4000, scale=0.1).numpy()
+    ref = (torch.from_numpy(est) * 0.8 + rnd(407, 4000, scale=0.03)).numpy()
+    want = float(sisdr(est, ref))
+    got = float(O.sisdr_np(est, ref))
+    print(f"  sisdr reference {want:.6f} oracle {got:.6f}")
+    assert abs(want - got) < 1e-5
+    save("op_sisdr", est=est, ref=ref, sisdr=np.float64(want))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "mini", "full"]
+    if "evalpath" in which:
+        gen_evalpath()
     if "ops" in which:
         gen_ops()
     if "mini" in which:

@@ -208,3 +208,19 @@ def test_oracle_backward_is_pinned_by_reference_gradients(golden, fixture, tol):
         assert float((got - want).norm()) / scale < (3 * tol if g.numel() == 1 else tol), name
         checked += 1
     assert checked > 100
+
+
+def test_evalpath_estimators_and_sisdr_golden(golden):
+    """the outtype estimators and SI-SDR restatements against outputs of the reference's own function bodies
+    (tests/golden/make_golden.py evalpath; test_se_cvaefinetune.py:85-135, utils/eval_metrics.py:49-64)."""
+    d = golden("op_outtype")
+    speech = torch.view_as_complex(torch.from_numpy(d["speech"]).contiguous())
+    noise = torch.view_as_complex(torch.from_numpy(d["noise"]).contiguous())
+    noisy = torch.from_numpy(d["noisy"])
+    for name, fn in (("real_imag_mask", O.outtype_real_imag_mask), ("complex_mask", O.outtype_complex_mask),
+                     ("phase_mask", O.outtype_phase_sensitive_mask)):
+        got = torch.view_as_real(fn(noise, speech, noisy))
+        want = torch.from_numpy(d[name])
+        assert float((got - want).norm() / want.norm()) < 1e-6, name
+    s = golden("op_sisdr")
+    assert abs(float(O.sisdr_np(s["est"], s["ref"])) - float(s["sisdr"])) < 1e-5
