@@ -32,7 +32,8 @@ struct GaussArgs {
     int Fin, Fout;
     int J, Jp, Tp;
     int Jp1, x1_div;
-    const float* wfrag;   // [cotiles][Cin_pad * 15][64]: k-step (ci, p, kf), lane = kt * 32 + co % 32
+    const float* wfrag;   // [cotiles][KS = Cin_pad * 15][64]: k-step (ci, p, kf), lane = kt * 32 + co % 32
+    int KS;               // k-steps per co tile as packed (Cin rounded up to the pack granularity)
     const float* epi;     // [cotiles * 32][8]: Zrr, Zri, Zir, Zii, sr, si, 0, 0   (no fold: 1, 0, 0, 1, b_re - b_im, b_re + b_im)
     int has_fold;
     const float* slope;
@@ -99,8 +100,8 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
     const int fbase = (MODE == IDV_CONV) ? 2 * fo0 - 2 : fo0 - 1;
 
     const int Cin = a.C0 + a.C1;
-    const int nchunk = (Cin + CIK - 1) / CIK;                // wfrag is zero padded to whole chunks
-    const int KS = nchunk * KSC;
+    const int nchunk = (Cin + CIK - 1) / CIK;                // wfrag is zero padded to whole chunks (of the pack granularity)
+    const int KS = a.KS;
 
     f32x16 acc[ROWS][JC_W][3];
 #pragma unroll
@@ -175,6 +176,11 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
     auto stage_store = [&](float* dst, int chunk) {
         const int ci0s = chunk * CIK;
         const int cvalid = (ci0s < a.C0 ? a.C0 : Cin) - ci0s;      // channels of this chunk that exist (ragged last chunk)
+        // every staged register is "used" here, outside the `e < NS` branch below: otherwise the threads that skip a slot
+        // never wait for its load, and hipcc protects the register's next writer with a near-complete vmcnt drain at the loop
+        // header -- which would expose the latency of the weight loads issued just before the back edge
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) asm volatile("" ::"v"(sr[i]), "v"(si[i]));
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * NT;
@@ -198,14 +204,12 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
         }
     };
 
-    // ---- weight fragments: one coalesced 256 B load per k-step, a whole chunk ahead
+    // ---- weight fragments: one coalesced 256 B load per k-step.  ONE register set: the five fragments of a unit are
+    // re-loaded with their next use after the unit's MFMAs have consumed them, i.e. (almost) a whole chunk ahead of their use
+    // and five loads per unit instead of a burst of KSC loads per chunk (the MFMA issue of a wave queues behind its own
+    // vector-memory issue: a 30-load burst cost the first version ~5 % of every chunk)
     const float* wbase = a.wfrag + (size_t)(ct_ok ? ct : 0) * KS * 64 + lane;
-    float a_cur[KSC], a_nxt[KSC];
-    auto load_a = [&](int chunk, float (&dst)[KSC]) {
-        const float* wch = wbase + (size_t)chunk * KSC * 64;
-#pragma unroll
-        for (int ks = 0; ks < KSC; ++ks) dst[ks] = wch[(size_t)ks * 64];
-    };
+    float a_w[KSC];
 
     // ---- activation fragments of one unit (one plane of one channel): FR rows x JC_W column tiles, one unit ahead
     const int bcol = wn * (JC_W * 32) + (lane & 31) + (lane >> 5) + COL0 + a.tshift;
@@ -217,15 +221,18 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
     };
 
     stage_load(0);
-    load_a(0, a_cur);
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) a_w[ks] = wbase[(size_t)ks * 64];
     stage_store(smem, 0);
 #pragma unroll
-    for (int ks = 0; ks < KSC; ++ks) asm volatile("" : "+v"(a_cur[ks]));      // retire the prologue loads before the loop
+    for (int ks = 0; ks < KSC; ++ks) asm volatile("" : "+v"(a_w[ks]));       // retire the prologue loads before the loop
     __syncthreads();
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const float* P = smem + (chunk & 1) * NE;
         const int nxt = (chunk + 1 < nchunk) ? chunk + 1 : chunk;            // branch-free: the last chunk re-fetches itself
+        const float* wnx = wbase + (size_t)nxt * KSC * 64;
+        const float* wcu = wbase + (size_t)chunk * KSC * 64;
         float b_cur[FR][JC_W], b_nxt[FR][JC_W];
         load_b(P, 0, b_cur);
 #pragma unroll
@@ -233,10 +240,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
             const int p3 = u % 3;
             if (u + 1 < UNITS) load_b(P, u + 1, b_nxt);
             __builtin_amdgcn_sched_barrier(0);
-            if (u == 0) {
-                stage_load(nxt);
-                load_a(nxt, a_nxt);
-            }
+            if (u == 0) stage_load(nxt);
             if (u == UNITS - 1) stage_store(smem + ((chunk + 1) & 1) * NE, nxt);
 #pragma unroll
             for (int kf = 0; kf < KF; ++kf) {
@@ -252,8 +256,19 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
                     }
 #pragma unroll
                     for (int jc = 0; jc < JC_W; ++jc)
-                        acc[rt][jc][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ks], b_cur[fr][jc], acc[rt][jc][p3], 0, 0, 0);
+                        acc[rt][jc][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[ks], b_cur[fr][jc], acc[rt][jc][p3], 0, 0, 0);
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the PREVIOUS unit's fragments are consumed: fetch its next use into the same registers (unit 0 fetches the last
+            // unit of THIS chunk, every other unit the next chunk's: rotated by one so that nothing loaded right before the
+            // loop's back edge is live across it -- the two values hipcc copies at the loop header are then old loads)
+#pragma unroll
+            for (int kf = 0; kf < KF; ++kf) {
+                if (u == 0)
+                    a_w[(UNITS - 1) * KF + kf] = wcu[(size_t)((UNITS - 1) * KF + kf) * 64];
+                else
+                    a_w[(u - 1) * KF + kf] = wnx[(size_t)((u - 1) * KF + kf) * 64];
             }
             if (u + 1 < UNITS) {
 #pragma unroll
@@ -262,8 +277,6 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
                     for (int jc = 0; jc < JC_W; ++jc) b_cur[fr][jc] = b_nxt[fr][jc];
             }
         }
-#pragma unroll
-        for (int ks = 0; ks < KSC; ++ks) a_cur[ks] = a_nxt[ks];
         __syncthreads();
     }
 
@@ -409,7 +422,9 @@ int launch_gauss(const GaussArgs& a, hipStream_t st) {
 
 inline int waste(int n, int t) { return ((n + t - 1) / t) * t - n; }
 
-constexpr int CIK = 2;
+constexpr int CIK = 4;        // complex input channels per K chunk (wfrag / supported() granularity); the kernels' own chunk
+constexpr int CIK5 = 2;       // the 5-row conv tile (15 accumulator tiles = 240 registers) and the 1-row x 4-column-tile conv
+                              // (13 / 5 patch rows of 72 / 264 .. 520 columns per channel) stage 2 channels per chunk
 
 // configuration id: 3 MODE WM WN FO_T JC_W as decimal digits (leading 3 = the three-product kernel)
 int gauss_config(int transposed, int Cout, int rows) {
@@ -428,12 +443,12 @@ int launch_cfg(const GaussArgs& a, int transposed, hipStream_t st) {
     switch (gauss_config(transposed, a.Cout, rows)) {
         case 312212: return launch_gauss<IDV_TCONV, 2, 2, 1, 2, CIK, STATS>(a, st);
         case 311412: return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
-        case 302251: return launch_gauss<IDV_CONV, 2, 2, 5, 1, CIK, STATS>(a, st);
+        case 302251: return launch_gauss<IDV_CONV, 2, 2, 5, 1, CIK5, STATS>(a, st);
         case 302231: return launch_gauss<IDV_CONV, 2, 2, 3, 1, CIK, STATS>(a, st);
-        case 302214: return launch_gauss<IDV_CONV, 2, 2, 1, 4, CIK, STATS>(a, st);
-        case 301451: return launch_gauss<IDV_CONV, 1, 4, 5, 1, CIK, STATS>(a, st);
+        case 302214: return launch_gauss<IDV_CONV, 2, 2, 1, 4, CIK5, STATS>(a, st);
+        case 301451: return launch_gauss<IDV_CONV, 1, 4, 5, 1, CIK5, STATS>(a, st);
         case 301431: return launch_gauss<IDV_CONV, 1, 4, 3, 1, CIK, STATS>(a, st);
-        case 301414: return launch_gauss<IDV_CONV, 1, 4, 1, 4, CIK, STATS>(a, st);
+        case 301414: return launch_gauss<IDV_CONV, 1, 4, 1, 4, CIK5, STATS>(a, st);
         default: return IDV_EINVAL;
     }
 }
@@ -496,7 +511,7 @@ extern "C" int idv_cconv2d_gauss_fwd(const float* x0, int C0, const float* x1, i
     a.Fin = Fin;
     a.Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
     a.J = B * Tp; a.Jp = Jp; a.Tp = Tp; a.Jp1 = C1 > 0 ? Jp1 : Jp; a.x1_div = x1_div < 1 ? 1 : x1_div;
-    a.wfrag = wfrag; a.epi = epi; a.has_fold = has_fold; a.slope = prelu_slope; a.out = out;
+    a.wfrag = wfrag; a.KS = (C0 + C1 + CIK - 1) / CIK * CIK * 15; a.epi = epi; a.has_fold = has_fold; a.slope = prelu_slope; a.out = out;
     a.Cout = Cout; a.cotiles = (Cout + 31) / 32;
     a.tshift = tshift; a.t_valid = t_valid_out; a.stats = stats;
     if (Jp < a.J) return IDV_EINVAL;
