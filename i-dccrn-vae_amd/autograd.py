@@ -171,7 +171,7 @@ def _dgrad(dy: Planar, w_re, w_im, cout_adj: int, cin_adj: int, fwd_transposed: 
             return ops.cconv2d_img(dy_img, w16, zb, cout_adj, transposed=adj_tr, causal=True, adjoint=True, want_planar=True,
                                    want_image=False)[0]
         return ops.cconv_dgrad(dy, None, zb, cout_adj, fwd_transposed, True, wfrag_bf16=w16)
-    if ops.PRECISION == "fp32" and ops.gauss_supported(cin_adj, 0, cout_adj):
+    if ops.PRECISION == "fp32" and ops.gauss_supported(cin_adj, 0, cout_adj, bwd=True):
         # exact fp32 with three real products per complex product (csrc/cgemm_gauss.hip)
         g3 = ops.pack_cconv_gauss(w_re, w_im, None, None, None, adjoint_of=(cout_adj, cin_adj, cin_adj, adj_tr))
         return ops.cconv_dgrad(dy, None, None, cout_adj, fwd_transposed, True, gauss=g3)

@@ -225,8 +225,14 @@ def pack_cconv(w_re, w_im, b_re, b_im, fold, cin_used: Optional[int] = None, tra
     return wfrag, bias
 
 
-def gauss_supported(c0: int, c1: int, cout: int) -> bool:
+GAUSS_FWD = os.environ.get("IDV_GAUSS_FWD", "1") != "0"      # A/B switches: forward / data gradient on cgemm_kernel instead
+GAUSS_BWD = os.environ.get("IDV_GAUSS_BWD", "1") != "0"
+
+
+def gauss_supported(c0: int, c1: int, cout: int, bwd: bool = False) -> bool:
     """fp32 mode: does the three-product (Gauss) contraction kernel serve this layer (csrc/cgemm_gauss.hip)?"""
+    if not (GAUSS_BWD if bwd else GAUSS_FWD):
+        return False
     return bool(L.lib().idv_cconv_gauss_supported(i(c0), i(c1), i(cout)))
 
 
