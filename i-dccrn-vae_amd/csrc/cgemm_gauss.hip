@@ -41,6 +41,9 @@ struct GaussArgs {
     int Cout, cotiles;
     int tshift, t_valid;
     double* stats;        // train mode: [Cout][5] sums (r, i, rr, ii, ri) of conv + bias, or nullptr
+    const float* add;     // optional addend, planar [2][Cout][Fout][add_Jp]: added to the contraction before bias / BN / PReLU;
+    int add_div, add_Jp;  //   column j of the output reads the addend's utterance b / add_div (a conv of the skip connection
+                          //   computed once per utterance and shared by its num_samples latent draws)
     int jtiles, ftiles, mblocks, map_ft;
 };
 
@@ -295,15 +298,20 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
 #pragma unroll
         for (int jc = 0; jc < JC_W; ++jc) {
             const int j = j0 + wn * (JC_W * 32) + jc * 32 + l31;
-            const int tp = j % a.Tp;
+            const int bj = j / a.Tp, tp = j - bj * a.Tp;
             const bool keep = (tp >= 1) && (tp <= a.t_valid);
             const bool inb = j < a.J;
+            const int ja = j - (bj - bj / a.add_div) * a.Tp;          // column of utterance b / add_div in the addend
 #pragma unroll
             for (int rt = 0; rt < ROWS; ++rt) {
                 const int fo = (MODE == IDV_TCONV) ? 2 * (fo0 + (rt >> 1)) + (rt & 1) : fo0 + rt;
                 if (fo >= a.Fout) continue;
                 const float t1 = acc[rt][jc][0][r], t2 = acc[rt][jc][1][r], t3 = acc[rt][jc][2][r];
-                const float re = t1 - t3, im = t1 + t2;
+                float re = t1 - t3, im = t1 + t2;
+                if (a.add && cok && inb) {
+                    re += a.add[((size_t)co * a.Fout + fo) * a.add_Jp + ja];
+                    im += a.add[((size_t)(a.Cout + co) * a.Fout + fo) * a.add_Jp + ja];
+                }
                 float yr, yi;
                 if (a.has_fold) {
                     yr = e0[0] * re + e0[1] * im + e4;
@@ -496,13 +504,17 @@ extern "C" int idv_pack_cconv_gauss(const float* w_re, const float* w_im, const 
 }
 
 // idv_cconv2d_fwd on the three-product kernel: same arguments, with (wfrag, epi) from idv_pack_cconv_gauss in place of
-// (wfrag, bias); has_fold != 0 applies the table's 2x2 map (eval-mode ComplexBatchNormal) before PReLU.  Reference:
+// (wfrag, bias); has_fold != 0 applies the table's 2x2 map (eval-mode ComplexBatchNormal) before PReLU.  addend (or NULL):
+// planar [2][Cout][Fout][addend_Jp] with B / addend_div utterances, added to the contraction before bias / BN / PReLU --
+// the convolution is linear in its input channels, so the skip half of a decoder block whose skips repeat per latent sample
+// (pvae_module.py:2563-2567) is computed once per utterance and added to every sample's latent half.  Reference:
 // model/complex_progress.py:16-22, :32-36, :244-250, :275-279 (+ :161-209 and pvae_module.py:58,82 for the epilogue).
 extern "C" int idv_cconv2d_gauss_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const float* wfrag,
                                      const float* epi, int has_fold, const float* prelu_slope, float* out, double* stats,
                                      int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out,
-                                     void* stream) {
+                                     const float* addend, int addend_div, int addend_Jp, void* stream) {
     if (!x0 || !wfrag || !epi || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    if (addend && (addend_div < 1 || B % addend_div || addend_Jp < (B / addend_div) * Tp || stats)) return IDV_EINVAL;
     if (C1 > 0 && (!x1 || x1_div < 1)) return IDV_EINVAL;
     if (tshift != 0 && tshift != -1) return IDV_EINVAL;
     if (!idv_cconv_gauss_supported(C0, C1, Cout)) return IDV_EINVAL;
@@ -514,6 +526,7 @@ extern "C" int idv_cconv2d_gauss_fwd(const float* x0, int C0, const float* x1, i
     a.wfrag = wfrag; a.KS = (C0 + C1 + CIK - 1) / CIK * CIK * 15; a.epi = epi; a.has_fold = has_fold; a.slope = prelu_slope; a.out = out;
     a.Cout = Cout; a.cotiles = (Cout + 31) / 32;
     a.tshift = tshift; a.t_valid = t_valid_out; a.stats = stats;
+    a.add = addend; a.add_div = addend ? addend_div : 1; a.add_Jp = addend_Jp;
     if (Jp < a.J) return IDV_EINVAL;
     // chunk-relative offsets are 32-bit: CIK channels of one source must stay below 2^32 floats (they do: 2 x 257 x Jp)
     if ((long long)CIK * Fin * (long long)(Jp > a.Jp1 ? Jp : a.Jp1) >= 0xffffffffLL) return IDV_EINVAL;

@@ -225,6 +225,7 @@ def pack_cconv(w_re, w_im, b_re, b_im, fold, cin_used: Optional[int] = None, tra
     return wfrag, bias
 
 
+SKIP_ONCE = os.environ.get("IDV_SKIP_ONCE", "1") != "0"      # fp32 eval, repeated skips: skip half of a decoder conv once per utterance
 GAUSS_FWD = os.environ.get("IDV_GAUSS_FWD", "1") != "0"      # A/B switches: forward / data gradient on cgemm_kernel instead
 GAUSS_BWD = os.environ.get("IDV_GAUSS_BWD", "1") != "0"
 
@@ -260,6 +261,20 @@ def pack_cconv_gauss(w_re, w_im, b_re, b_im, fold, cin_used: Optional[int] = Non
     call("idv_pack_cconv_gauss", p(w_re.contiguous()), p(w_im.contiguous()), p(b_re.contiguous()), p(b_im.contiguous()), p(fold),
          i(cout), i(cin_total), i(cin_used), i(1 if transposed else 0), i(0), p(wfrag), p(epi), stream_ptr())
     return wfrag, epi, (1 if fold is not None else 0)
+
+
+def pack_cconv_gauss_skip_part(w_re, w_im, c0: int):
+    """Gauss operands of the SKIP half of a transposed conv [Cin][Cout][5][2] (input channels c0 .. Cin), no bias, no fold:
+    the once-per-utterance addend of the repeated-skip decoder (see cconv2d(addend=...))."""
+    wr, wi = w_re[c0:].contiguous(), w_im[c0:].contiguous()
+    cin, cout = wr.shape[0], wr.shape[1]
+    lib = L.lib()
+    lib.idv_cconv_gauss_wfrag_floats.restype = L._L
+    wfrag = torch.empty(int(lib.idv_cconv_gauss_wfrag_floats(i(cout), i(cin))), dtype=torch.float32, device=wr.device)
+    epi = torch.empty(int(lib.idv_cconv_gauss_epi_rows(i(cout))) * 8, dtype=torch.float32, device=wr.device)
+    call("idv_pack_cconv_gauss", p(wr), p(wi), p(None), p(None), p(None), i(cout), i(cin), i(cin), i(1), i(0), p(wfrag), p(epi),
+         stream_ptr())
+    return wfrag, epi, 0
 
 
 def bf16_supported(transposed: bool, c0: int, c1: int, skip_div: int, cout: int) -> bool:
@@ -393,7 +408,8 @@ def concurrent(fns, device=None):
 
 def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True, slope=None, skip: Optional[Planar] = None,
             skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None,
-            wfrag_bf16: Optional[torch.Tensor] = None, image: str = "", adjoint_time: bool = False, gauss=None):
+            wfrag_bf16: Optional[torch.Tensor] = None, image: str = "", adjoint_time: bool = False, gauss=None,
+            addend: Optional[Planar] = None, addend_div: int = 1):
     """(causal_)ComplexConv2d / (causal_)ComplexConvTranspose2d forward on planar activations.
     image="also" / "only": the exact-fp32 kernel additionally / only writes a split-bf16 image -> (Planar|None, Image)."""
     Fout = 2 * x.F - 1 if transposed else (x.F - 1) // 2 + 1
@@ -442,7 +458,8 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
             cfg = L.lib().idv_cconv_gauss_config(i(1 if transposed else 0), i(cout), i(x.F))
         call("idv_cconv2d_gauss_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
              i(skip.Jp if skip is not None else 0), i(skip_div), p(gauss[0]), p(gauss[1]), i(gauss[2]), p(slope), out.ptr(),
-             p(stats), i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+             p(stats), i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out),
+             addend.ptr() if addend is not None else p(None), i(addend_div), i(addend.Jp if addend is not None else 0), stream_ptr())
     else:
         call("idv_cconv2d_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
              i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag), p(bias), p(slope), out.ptr(), p(stats),
@@ -834,7 +851,7 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
             cfg = L.lib().idv_cconv_gauss_config(i(1 if adj_transposed else 0), i(cout_adj), i(dy.F))
         call("idv_cconv2d_gauss_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(gauss[0]), p(gauss[1]), i(0), p(None),
              out.ptr(), p(None), i(1 if adj_transposed else 0), i(0), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(dy.T),
-             stream_ptr())
+             p(None), i(1), i(0), stream_ptr())
     else:
         call("idv_cconv2d_bf16x3_fwd" if wfrag_bf16 is not None else "idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1),
              p(wfrag_bf16 if wfrag_bf16 is not None else wfrag), p(bias), p(None), out.ptr(), p(None),

@@ -107,6 +107,10 @@ int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, i
  * eval-mode ComplexBatchNormal (fold, complex_progress.py:161-209) is a real 2x2 map, so it cannot be folded into the three
  * weight planes and is applied by the epilogue when has_fold != 0 (then PReLU, pvae_module.py:58,82).  conj != 0 packs the
  * adjoint (data-gradient) operator: W_i negated, the caller passes the swapped channel roles as for idv_pack_cconv_adjoint.
+ * addend (or NULL; eval only): planar [2][Cout][Fout][addend_Jp] holding B / addend_div utterances, added to the contraction
+ * before bias / BN / PReLU: output utterance b takes addend utterance b / addend_div.  The convolution is linear in its input
+ * channels, so for the repeated skips of pvae_module.py:2563-2567 the skip half is computed ONCE per utterance (a call with
+ * x0 = skip, the skip rows of the weight, no bias) and added to each of its num_samples latent halves.
  * idv_cconv_gauss_config: the kernel instantiation as digits 3 MODE WM WN FO_T JC_W (profiles). */
 int idv_cconv_gauss_supported(int C0, int C1, int Cout);
 long long idv_cconv_gauss_wfrag_floats(int Cout, int cin_used);
@@ -116,7 +120,8 @@ int idv_pack_cconv_gauss(const float* w_re, const float* w_im, const float* b_re
                          int Cin_total, int Cin_used, int transposed, int conj, float* wfrag, float* epi, void* stream);
 int idv_cconv2d_gauss_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const float* wfrag,
                           const float* epi, int has_fold, const float* prelu_slope, float* out, double* stats, int transposed,
-                          int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
+                          int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, const float* addend,
+                          int addend_div, int addend_Jp, void* stream);
 
 /* Split-precision variant of idv_cconv2d_fwd (same reference lines): operands split into two bf16 (x = hi + lo),
  * w*x ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi accumulated in fp32 on the bf16 MFMA (relative error ~2^-16 per

@@ -731,7 +731,7 @@ def _full_width(pm, nl):
     print(f"input gradient vs float64: HIP {ours:.2e}, float32 oracle {ref32:.2e}")
     assert ours < 1e-2
     n, worst = 0, (0.0, "", 0.0)
-    table, sq = {}, [0.0, 0.0, 0.0]
+    table, sq, viol = {}, [0.0, 0.0, 0.0], []
     for k, p_ in m.named_parameters():
         want = sd[k].grad
         if want is None:
@@ -749,7 +749,8 @@ def _full_width(pm, nl):
         # with a floor where the float32 oracle happens to be flip-free
         k_, floor = YARD[ops_precision()]
         if p_.numel() > 1:
-            assert ours <= max(k_ * ref32, floor), (k, ours, ref32)
+            if ours > max(k_ * ref32, floor):
+                viol.append((k, ours, ref32))
             wn = float(want.double().norm())
             sq[0] += (ours * wn) ** 2
             sq[1] += (ref32 * wn) ** 2
@@ -763,7 +764,8 @@ def _full_width(pm, nl):
     tot_ours, tot_ref = (sq[0] / sq[2]) ** 0.5, (sq[1] / sq[2]) ** 0.5
     print(f"whole gradient vector vs float64: HIP {tot_ours:.2e}, float32 oracle {tot_ref:.2e}")
     _dump(f"grad_f64_full_{ops_precision()}", {"table": table, "total": [tot_ours, tot_ref]})
-    assert tot_ours <= max(YARD[ops_precision()][0] * tot_ref, 1e-3), (tot_ours, tot_ref)
+    assert not viol, viol
+    assert tot_ours <= max(3.0 * tot_ref, 1e-3), (tot_ours, tot_ref)
 
 
 YARD = {"fp32": (3.0, 1e-3), "bf16x3": (10.0, 3e-3)}

@@ -528,7 +528,7 @@ def test_two_latent_evaluation_path(pm, outtype, phase):
             return O.vae_decoder_forward(oe["stft_x"], z, oe["skiper"], 8 * base, 5, sd_d, np_, True, ns, NFFT, HOP, WIN, "mask", SKIP,
                                          "sig", True, False)
         return O.vae_decoder_forward(oe["stft_x"], z, oe["skiper"], 8 * base, 5, sd_d, np_, True, ns, NFFT, HOP, WIN, "real_imag", SKIP,
-                                     "zero", False, False)
+                                     "zero", True, False)
     rec_s, pred_s = odec(dec_s, oe["z_speech"])
     if outtype == "clean_direct":
         want = rec_s.view(B, ns, -1).mean(1)

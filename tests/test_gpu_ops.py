@@ -137,6 +137,35 @@ def test_cconv_gauss_stats_and_adjoint(ops):
         assert relerr(d1.tensor5().cpu(), d0.tensor5().cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("ns,B0,c0,c1,cout,F,T", [(2, 3, 8, 8, 12, 9, 30), (5, 2, 16, 16, 40, 17, 21), (3, 1, 4, 6, 4, 33, 45)])
+def test_cconv_gauss_skip_half_once(ops, ns, B0, c0, c1, cout, F, T):
+    """Repeated skips (pvae_module.py:2563-2567): the skip half of the transposed conv computed once per utterance and added in
+    the epilogue (idv_cconv2d_gauss_fwd addend) against the oracle on the materialised repeat, with fold + PReLU."""
+    g = torch.Generator().manual_seed(31 + ns)
+    dev = "cuda"
+    x = torch.randn(B0 * ns, c0, F, T, 2, generator=g)
+    sk = torch.randn(B0, c1, F, T, 2, generator=g)
+    wr, wi = torch.randn(c0 + c1, cout, 5, 2, generator=g) * 0.2, torch.randn(c0 + c1, cout, 5, 2, generator=g) * 0.2
+    br, bi = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    want = O.complex_conv_transpose2d(torch.cat([x, sk.repeat_interleave(ns, dim=0)], dim=1), wr, br, wi, bi, (2, 1), (2, 0), True)
+    mom = torch.stack([torch.randn(cout, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1, 0.5 + torch.rand(cout, generator=g),
+                       0.1 * torch.randn(cout, generator=g), 0.5 + torch.rand(cout, generator=g)])
+    gam = [1 + 0.1 * torch.randn(cout, generator=g), torch.randn(cout, generator=g), 1 + 0.1 * torch.randn(cout, generator=g)]
+    bet = [0.1 * torch.randn(cout, generator=g), 0.1 * torch.randn(cout, generator=g)]
+    want = O.prelu(O.cbn_whiten_affine(want, mom[0], mom[1], mom[2], mom[3], mom[4], gam[0], gam[1], gam[2], bet[0], bet[1]),
+                   torch.tensor(0.2))
+    fold = ops.cbn_fold(mom.to(dev), *[t.to(dev) for t in gam], *[t.to(dev) for t in bet])
+    slope = torch.tensor([0.2], device=dev)
+    xp, skp = ops.Planar.from_tensor5(x.to(dev), T + 1), ops.Planar.from_tensor5(sk.to(dev), T + 1)
+    wr_d, wi_d = wr.to(dev), wi.to(dev)
+    g_skip = ops.pack_cconv_gauss_skip_part(wr_d, wi_d, c0)
+    y_skip = ops.cconv2d(skp, None, None, cout, transposed=True, gauss=g_skip)
+    g_main = ops.pack_cconv_gauss(wr_d, wi_d, br.to(dev), bi.to(dev), fold, cin_used=c0, transposed=True)
+    y = ops.cconv2d(xp, None, None, cout, transposed=True, slope=slope, gauss=g_main, addend=y_skip, addend_div=ns)
+    assert relerr(y.tensor5().cpu(), want) < TOL
+    assert float(y.planes()[..., 0].abs().max()) == 0.0
+
+
 def test_cconv_fold_prelu(ops):
     _conv_case(ops, True, False, 8, 16, 33, 21, 2, seed=2, fold=True, slope=0.2)
     _conv_case(ops, True, True, 8, 16, 9, 21, 2, seed=3, fold=True, slope=0.3)
