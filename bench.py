@@ -332,7 +332,11 @@ def kernel_name(cfg_id):
         return "void (anonymous namespace)::ctconv_c1_f32_kernel<false>(CgemmArgs, int)"
     if 300000 <= cfg_id < 400000:       # idv_cconv_gauss_config digits 3 MODE WM WN FO_T JC_W
         d = str(cfg_id)
-        return (f"void (anonymous namespace)::cgemm_gauss_kernel<{d[1]}, {d[2]}, {d[3]}, {d[4]}, {d[5]}, 2, false, true>"
+        cik = 2 if (d[1] == "0" and d[4] in "15") else 4                  # cgemm_gauss.hip launch_cfg: CIK5 for the 5- and 1-row conv tiles
+        jt = 32 * int(d[5]) * int(d[3])
+        fr = 2 * int(d[4]) + 3 if d[1] == "0" else int(d[4]) + 2
+        nbuf = 3 if 3 * cik * 3 * fr * (jt + 8) * 4 <= 156 * 1024 else 2
+        return (f"void (anonymous namespace)::cgemm_gauss_kernel<{d[1]}, {d[2]}, {d[3]}, {d[4]}, {d[5]}, {cik}, false, true, {nbuf}>"
                 "((anonymous namespace)::GaussArgs)")
     if cfg_id > 0:
         d = str(cfg_id)

@@ -53,7 +53,13 @@ struct GaussGeom {
     static constexpr int ROWS = (MODE == IDV_TCONV) ? 2 * FO_T : FO_T;
 };
 
-template <int MODE, int WM, int WN, int FO_T, int JC_W, int CIK, bool STATS, bool VEC>
+// NBUF: LDS patch buffers.  2: the next chunk is written during the last unit, one barrier at the chunk's end, the first
+// fragments of the next chunk are read behind it (their LDS latency + the store's vector work sit between two MFMAs).
+// 3 (where 3 patches fit the 160 KB): the next chunk is written in the MIDDLE of the chunk, the barrier stands in front of
+// the last unit and the next chunk's first fragments are read during the last unit's MFMAs -- nothing waits at the chunk
+// boundary.  Three buffers because a wave that has passed barrier(c-1) may write chunk c+1's patch while a slower wave still
+// reads chunk c-1's in its last unit: they must be different buffers.
+template <int MODE, int WM, int WN, int FO_T, int JC_W, int CIK, bool STATS, bool VEC, int NBUF>
 __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const GaussArgs a) {
     using G = GaussGeom<MODE, FO_T>;
     constexpr int NT = WM * WN * 64;
@@ -231,22 +237,22 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
     for (int ks = 0; ks < KSC; ++ks) asm volatile("" : "+v"(a_w[ks]));       // retire the prologue loads before the loop
     __syncthreads();
 
+    constexpr int UMID = UNITS / 2;
+    float b_cur[FR][JC_W], b_nxt[FR][JC_W];
+    int ibuf = 0;                                                             // buffer of the current chunk
+    if (NBUF == 3) load_b(smem, 0, b_cur);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-        const float* P = smem + (chunk & 1) * NE;
+        const float* P = smem + ibuf * NE;
+        const int inext = (ibuf + 1 == NBUF) ? 0 : ibuf + 1;
+        float* Pn = smem + inext * NE;
         const int nxt = (chunk + 1 < nchunk) ? chunk + 1 : chunk;            // branch-free: the last chunk re-fetches itself
         const float* wnx = wbase + (size_t)nxt * KSC * 64;
         const float* wcu = wbase + (size_t)chunk * KSC * 64;
-        float b_cur[FR][JC_W], b_nxt[FR][JC_W];
-        load_b(P, 0, b_cur);
+        if (NBUF == 2) load_b(P, 0, b_cur);
 #pragma unroll
         for (int u = 0; u < UNITS; ++u) {
             const int p3 = u % 3;
-            if (u + 1 < UNITS) load_b(P, u + 1, b_nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            if (u == 0) stage_load(nxt);
-            if (u == UNITS - 1) stage_store(smem + ((chunk + 1) & 1) * NE, nxt);
-#pragma unroll
-            for (int kf = 0; kf < KF; ++kf) {
+            auto mfma_tap = [&](int kf) {
                 const int ks = u * KF + kf;
 #pragma unroll
                 for (int rt = 0; rt < ROWS; ++rt) {
@@ -261,7 +267,21 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
                     for (int jc = 0; jc < JC_W; ++jc)
                         acc[rt][jc][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[ks], b_cur[fr][jc], acc[rt][jc][p3], 0, 0, 0);
                 }
-            }
+            };
+            // the unit's first tap goes BEFORE the next unit's LDS reads: at the loop header the fragments carried over the
+            // back edge then need no wait (hipcc waits with lgkmcnt(0) there: behind freshly issued reads that is their latency)
+            mfma_tap(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NBUF == 3 && u == UNITS - 1) __syncthreads();                // every wave has written the next chunk's patch
+            if (u + 1 < UNITS)
+                load_b(P, u + 1, b_nxt);
+            else if (NBUF == 3)
+                load_b(Pn, 0, b_nxt);                                        // the next chunk's first unit
+            __builtin_amdgcn_sched_barrier(0);
+            if (u == 0) stage_load(nxt);
+            if (u == (NBUF == 3 ? UMID : UNITS - 1)) stage_store(Pn, nxt);
+#pragma unroll
+            for (int kf = 1; kf < KF; ++kf) mfma_tap(kf);
             __builtin_amdgcn_sched_barrier(0);
             // the PREVIOUS unit's fragments are consumed: fetch its next use into the same registers (unit 0 fetches the last
             // unit of THIS chunk, every other unit the next chunk's: rotated by one so that nothing loaded right before the
@@ -273,14 +293,15 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const Gauss
                 else
                     a_w[(u - 1) * KF + kf] = wnx[(size_t)((u - 1) * KF + kf) * 64];
             }
-            if (u + 1 < UNITS) {
+            if (u + 1 < UNITS || NBUF == 3) {
 #pragma unroll
                 for (int fr = 0; fr < FR; ++fr)
 #pragma unroll
                     for (int jc = 0; jc < JC_W; ++jc) b_cur[fr][jc] = b_nxt[fr][jc];
             }
         }
-        __syncthreads();
+        if (NBUF == 2) __syncthreads();
+        ibuf = inext;
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -400,7 +421,8 @@ int launch_gauss_v(const GaussArgs& a, hipStream_t st) {
     using G = GaussGeom<MODE, FO_T>;
     constexpr int JT = 32 * JC_W * WN;
     constexpr int NE = CIK * 3 * G::FR * (JT + 8);
-    constexpr size_t smem = 2 * NE * sizeof(float);
+    constexpr int NBUF = (3 * NE * sizeof(float) <= 156 * 1024) ? 3 : 2;     // three patch buffers where the LDS holds them
+    constexpr size_t smem = NBUF * NE * sizeof(float);
     const int rows = (MODE == IDV_TCONV) ? a.Fin : a.Fout;
     GaussArgs b = a;
     b.jtiles = (a.J + JT - 1) / JT;
@@ -411,7 +433,7 @@ int launch_gauss_v(const GaussArgs& a, hipStream_t st) {
     const long long tiles = (long long)b.jtiles * b.ftiles;
     const long long nblk = b.map_ft ? (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks : ((tiles + 7) / 8) * 8 * b.mblocks;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = cgemm_gauss_kernel<MODE, WM, WN, FO_T, JC_W, CIK, STATS, VEC>;
+    auto k = cgemm_gauss_kernel<MODE, WM, WN, FO_T, JC_W, CIK, STATS, VEC, NBUF>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return IDV_ELAUNCH;

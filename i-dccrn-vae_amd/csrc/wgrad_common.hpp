@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 
 namespace {
 
@@ -27,7 +28,10 @@ inline Plan make_plan(int Sp, int Lp, int J, int MS, int ML, int JT) {
     p.SpPad = p.tilesS * MS;
     p.LpPad = p.tilesL * ML;
     p.jtiles = (J + JT - 1) / JT;
-    int want = (1024 + p.tilesS * p.tilesL - 1) / (p.tilesS * p.tilesL);
+    // workgroups aimed at (two per CU are resident): more, shorter workgroups even out the last round at the price of more
+    // partial tiles for the unpack kernel to sum (IDV_WGRAD_WGS overrides, experiments)
+    static const int target = [] { const char* e = getenv("IDV_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    int want = (target + p.tilesS * p.tilesL - 1) / (p.tilesS * p.tilesL);
     if (want < 1) want = 1;
     if (want > p.jtiles) want = p.jtiles;
     p.jt_per_split = (p.jtiles + want - 1) / want;
