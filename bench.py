@@ -373,7 +373,7 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
     peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     ach = 2 * macs / secs / 1e12
     traffic, tsrc = None, None
-    tname = "r02_traffic_f32.json" if precision == "fp32" else "r02_traffic_bf16x3.json"
+    tname = "r03_traffic_f32.json" if precision == "fp32" else "r03_traffic_bf16x3.json"
     tpath = os.path.join(ROOT, "profiles", tname)
     if os.path.exists(tpath) and batch == DEFAULT_BATCH and workload == "dccrn_cl":
         tk = json.load(open(tpath))["kernels"].get(kernel_name(dom))
