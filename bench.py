@@ -322,6 +322,9 @@ TRAIN_WORKLOADS = ("dccrn_cl_train", "cvae_train", "nsvae_train", "twophase_trai
 
 
 def kernel_name(cfg_id):
+    if cfg_id == -95:
+        return ("void (anonymous namespace)::wgrad_kernel<5, 2, 1, 1, 4, 1, 16, 2>(WgradArgs) x 3 Gauss products + wgrad_combine_kernel + "
+                "wgrad_unpack_gauss_kernel")
     if cfg_id == -97:
         return "void (anonymous namespace)::wgrad_kernel<5, 2, 1, 1, 4, 1, 16, 2>(WgradArgs) + wgrad_unpack_conv_kernel"
     if cfg_id == -96:
@@ -369,7 +372,7 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
     macs, secs, n = groups[dom]
     tot_macs = sum(g[0] for g in groups.values())
     tot_secs = sum(g[1] for g in groups.values())
-    split = dom < 0 and dom != -97
+    split = dom < 0 and dom not in (-97, -95)
     peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     ach = 2 * macs / secs / 1e12
     traffic, tsrc = None, None
@@ -395,7 +398,7 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
         "per_kernel": {kernel_name(k): {"tflops": round(2 * v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3)}
                        for k, v in sorted(groups.items())},
     }
-    if 300000 <= dom < 400000:
+    if 300000 <= dom < 400000 or dom == -95:
         # three real products per complex product (Gauss, cgemm_gauss.hip): `achieved` counts the reference's 4 real convolutions
         r["executed"] = round(0.75 * ach, 3)
         r["frac_executed"] = round(0.75 * ach / peak, 4)

@@ -51,7 +51,14 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
-    const int split = blockIdx.x, ts = blockIdx.y, tl = blockIdx.z;
+    const int split = blockIdx.x, ts = blockIdx.y;
+    int tl = blockIdx.z, prod = 0;
+    if (a.nprod > 1) {
+        prod = tl / a.tilesL;
+        tl -= prod * a.tilesL;
+    }
+    const float* __restrict__ Sg = a.nprod > 1 ? a.Sx[prod] : a.S;
+    const float* __restrict__ Lg = a.nprod > 1 ? a.Lx[prod] : a.L;
     const int sp0 = ts * MS, lp0 = tl * ML;
     const int jt0 = split * a.jt_per_split;
     int jt1 = jt0 + a.jt_per_split;
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
             const int sp = sp0 + row, j = j0 + 4 * q;
             const bool ok = (e < S_SLOTS) && (sp < a.Sp) && (j < a.J);
             const size_t off = ok ? ((size_t)sp * a.Fs + fs) * a.JpS + j : 0;
-            sreg[i] = *(const f32x4*)(a.S + off);
+            sreg[i] = *(const f32x4*)(Sg + off);
         }
 #pragma unroll
         for (int i = 0; i < NL4; ++i) {
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
             const int lp = lp0 + pl, fl = (KF == 1) ? fs : 2 * fs + kf - 2, j = j0 + 4 * q;
             const bool ok = (e < L_SLOTS) && (lp < a.Lp) && (fl >= 0) && (fl < a.Fl) && (j < a.J);
             const size_t off = ok ? ((size_t)lp * a.Fl + fl) * a.JpL + j : 0;
-            lreg[i] = *(const f32x4*)(a.L + off);
+            lreg[i] = *(const f32x4*)(Lg + off);
         }
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
             const int j = side ? j0 + WG_JT : j0 - 1;
             const bool ok = (e < L_ROWS * 2) && (lp < a.Lp) && (fl >= 0) && (fl < a.Fl) && (j >= 0) && (j < a.J);
             const size_t off = ok ? ((size_t)lp * a.Fl + fl) * a.JpL + j : 0;
-            hreg[i] = a.L[off];
+            hreg[i] = Lg[off];
         }
     };
     auto store_step = [&](int step) {
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
     }
 
     // partial tile -> workspace (every slot of the padded tile is written, so the workspace needs no clearing)
-    float* P = a.part + (size_t)split * TAPS * a.SpPad * a.LpPad;
+    float* P = a.part + (size_t)prod * a.prod_stride + (size_t)split * TAPS * a.SpPad * a.LpPad;
 #pragma unroll
     for (int i = 0; i < MT_W; ++i)
 #pragma unroll
@@ -234,6 +241,54 @@ __global__ void wgrad_unpack_conv_kernel(const float* __restrict__ part, int nsp
         // conv: S = dy, L = x;  transposed conv: S = x, L = dy
         const double dwr = rr + ii;
         const double dwi = transposed ? (ri - ir) : (ir - ri);
+        const int co = transposed ? lc : sc, ci = ci_off + (transposed ? sc : lc);
+        const size_t o = transposed ? (((size_t)ci * Cout + co) * 10 + tap) : (((size_t)co * Cin_total + ci) * 10 + tap);
+        dw_re[o] = (float)dwr;
+        dw_im[o] = (float)dwi;
+    }
+}
+
+// ---- three-product (Gauss) form of the complex weight gradient -------------------------------------------------------------
+// With (p, q) the real / imaginary planes of an S channel and (u, v) those of an L channel, the complex weight gradient needs
+//   dWr = p u + q v,   dWi = q u - p v  (conv; transposed conv: p v - q u)      -- four real contractions per channel pair.
+// Gauss:  k1 = (p + q) u,  k2 = p (u + v),  k3 = q (u - v):   dWr = k1 - k3,  dWi = k1 - k2 (conv) / k2 - k1 (transposed):
+// three contractions, each between Cs x Cl REAL planes -- the wgrad_kernel as it is, launched once with three (S, L) operand
+// pairs.  The combined planes (p + q), (u + v), (u - v) are written once per call by an elementwise pass (HBM-bound, ~3 % of
+// the contraction's time); this kernel sums the split-K partials of the three products and applies the signs.
+__global__ void wgrad_combine_kernel(const float* __restrict__ re, const float* __restrict__ im, long long n4,
+                                     float* __restrict__ sum, float* __restrict__ diff) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 a = ((const f32x4*)re)[i], b = ((const f32x4*)im)[i];
+        f32x4 s4, d4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s4[c] = a[c] + b[c];
+            d4[c] = a[c] - b[c];
+        }
+        ((f32x4*)sum)[i] = s4;
+        if (diff) ((f32x4*)diff)[i] = d4;
+    }
+}
+
+__global__ void wgrad_unpack_gauss_kernel(const float* __restrict__ part, long long prod_stride, int nsplit, int SpPad, int LpPad,
+                                          int Cout, int Cx, int Cin_total, int ci_off, int transposed, float* __restrict__ dw_re,
+                                          float* __restrict__ dw_im) {
+    const int Cs = transposed ? Cx : Cout, Cl = transposed ? Cout : Cx;
+    const long long n = (long long)Cs * Cl * 10;
+    const size_t plane = (size_t)SpPad * LpPad;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int lc = (int)(idx % Cl);
+        const int sc = (int)((idx / Cl) % Cs);
+        const int tap = (int)(idx / ((long long)Cl * Cs));
+        double k1 = 0, k2 = 0, k3 = 0;
+        for (int sidx = 0; sidx < nsplit; ++sidx) {
+            const float* P = part + ((size_t)sidx * 10 + tap) * plane + (size_t)sc * LpPad + lc;
+            k1 += P[0];
+            k2 += P[prod_stride];
+            k3 += P[2 * prod_stride];
+        }
+        const double dwr = k1 - k3;
+        const double dwi = transposed ? (k2 - k1) : (k1 - k2);
         const int co = transposed ? lc : sc, ci = ci_off + (transposed ? sc : lc);
         const size_t o = transposed ? (((size_t)ci * Cout + co) * 10 + tap) : (((size_t)co * Cin_total + ci) * 10 + tap);
         dw_re[o] = (float)dwr;
@@ -444,6 +499,93 @@ extern "C" int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const 
     hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 4, 1, CONV_JT, 2>), dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_unpack_conv_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work, p.nsplit,
                        p.SpPad, p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
+    return idv_launch_status();
+}
+
+// ---- Gauss form: entry points -----------------------------------------------------------------------------------------------
+namespace {
+const bool WGRAD_GAUSS = [] { const char* e = getenv("IDV_WGRAD_GAUSS"); return !e || e[0] != '0'; }();
+// S tile of 128 planes x L tile of 32, or 64 x 64 where the S side has at most 64 planes
+inline bool gauss_tile64(int Cs) { return Cs <= 64; }
+struct GaussPlan { Plan p; long long prod_stride, part_floats, s_sum, l_each; };
+inline GaussPlan gauss_plan(int Cs, int Cl, int Fs, int Fl, int J, int JpS, int JpL) {
+    GaussPlan g;
+    g.p = gauss_tile64(Cs) ? make_plan(Cs, Cl, J, 64, 64, CONV_JT) : make_plan(Cs, Cl, J, CONV_MS, CONV_ML, CONV_JT);
+    // make_plan aims its workgroup count at ONE contraction; there are three in the launch
+    g.prod_stride = (long long)g.p.nsplit * 10 * g.p.SpPad * g.p.LpPad;
+    g.part_floats = 3 * g.prod_stride;
+    g.s_sum = ((long long)Cs * Fs * JpS + 63) / 64 * 64;
+    g.l_each = ((long long)Cl * Fl * JpL + 63) / 64 * 64;
+    return g;
+}
+}  // namespace
+
+// 1 if idv_cconv2d_bwd_weight_gauss serves the layer (>= 32 complex channels on both sides; IDV_WGRAD_GAUSS=0 turns it off)
+extern "C" int idv_cconv_wgrad_gauss_supported(int Cs, int Cl) { return WGRAD_GAUSS && Cs >= 32 && Cl >= 32; }
+
+// work floats of idv_cconv2d_bwd_weight_gauss: split-K partials of the three products + the combined planes (p + q | u + v | u - v)
+extern "C" long long idv_cconv_wgrad_gauss_work_floats(int Cx, int Cout, int transposed, int Fin, int B, int Tp, int Jp_x, int Jp_dy) {
+    if (Cx <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 0) return -1;
+    const int Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
+    const int Cs = transposed ? Cx : Cout, Cl = transposed ? Cout : Cx;
+    const int Fs = transposed ? Fin : Fout, Fl = transposed ? Fout : Fin;
+    const GaussPlan g = gauss_plan(Cs, Cl, Fs, Fl, B * Tp, transposed ? Jp_x : Jp_dy, transposed ? Jp_dy : Jp_x);
+    return g.part_floats + g.s_sum + 2 * g.l_each;
+}
+
+// idv_cconv2d_bwd_weight with three real contractions per complex channel pair instead of four (same arguments, same result up
+// to fp32 rounding; reference: torch.autograd of nn.Conv2d / nn.ConvTranspose2d in model/complex_progress.py:8-36, :222-279).
+// work: idv_cconv_wgrad_gauss_work_floats floats, 16-byte aligned.
+extern "C" int idv_cconv2d_bwd_weight_gauss(const float* x, int Cx, int ci_off, const float* dy, int Cout, int Cin_total,
+                                            int transposed, int tshift, int Fin, int B, int Tp, int Jp_x, int Jp_dy, float* work,
+                                            long long work_floats, float* dw_re, float* dw_im, void* stream) {
+    if (!x || !dy || !work || !dw_re || !dw_im || Cx <= 0 || Cout <= 0 || ci_off < 0 || ci_off + Cx > Cin_total || Fin <= 0 ||
+        B <= 0 || Tp <= 1)
+        return IDV_EINVAL;
+    if ((tshift != 0 && tshift != -1) || (Jp_x % 4) || (Jp_dy % 4) || !aligned16(x) || !aligned16(dy) || !aligned16(work) ||
+        Jp_x < B * Tp || Jp_dy < B * Tp)
+        return IDV_EINVAL;
+    const int Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
+    if (!transposed && 2 * Fout - 1 != Fin) return IDV_EINVAL;
+    WgradArgs a{};
+    const float* S; const float* L;
+    int Cs, Cl;
+    if (!transposed) {      // S = dy [2 Cout][Fout], L = x [2 Cx][Fin]
+        S = dy; Cs = Cout; a.Fs = Fout; a.JpS = Jp_dy;
+        L = x;  Cl = Cx;   a.Fl = Fin;  a.JpL = Jp_x;
+        a.dt0 = tshift;
+    } else {                // S = x [2 Cx][Fin], L = dy [2 Cout][Fout]
+        S = x;  Cs = Cx;   a.Fs = Fin;  a.JpS = Jp_x;
+        L = dy; Cl = Cout; a.Fl = Fout; a.JpL = Jp_dy;
+        a.dt0 = 0;
+    }
+    if (!idv_cconv_wgrad_gauss_supported(Cs, Cl)) return IDV_EINVAL;
+    a.J = B * Tp;
+    a.Sp = Cs; a.Lp = Cl;
+    const GaussPlan g = gauss_plan(Cs, Cl, a.Fs, a.Fl, a.J, a.JpS, a.JpL);
+    if (g.part_floats + g.s_sum + 2 * g.l_each > work_floats) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float* s_sum = work + g.part_floats;
+    float* l_sum = s_sum + g.s_sum;
+    float* l_dif = l_sum + g.l_each;
+    const long long ns4 = (long long)Cs * a.Fs * a.JpS / 4, nl4 = (long long)Cl * a.Fl * a.JpL / 4;
+    const float* S_im = S + (size_t)Cs * a.Fs * a.JpS;
+    const float* L_im = L + (size_t)Cl * a.Fl * a.JpL;
+    hipLaunchKernelGGL(wgrad_combine_kernel, dim3(grid_for(ns4)), dim3(256), 0, st, S, S_im, ns4, s_sum, (float*)nullptr);
+    hipLaunchKernelGGL(wgrad_combine_kernel, dim3(grid_for(nl4)), dim3(256), 0, st, L, L_im, nl4, l_sum, l_dif);
+    a.S = S; a.L = L;
+    a.Sx[0] = s_sum; a.Lx[0] = L;        // k1 = (p + q) u
+    a.Sx[1] = S;     a.Lx[1] = l_sum;    // k2 = p (u + v)
+    a.Sx[2] = S_im;  a.Lx[2] = l_dif;    // k3 = q (u - v)
+    a.nprod = 3; a.tilesL = g.p.tilesL; a.prod_stride = g.prod_stride;
+    a.part = work; a.SpPad = g.p.SpPad; a.LpPad = g.p.LpPad; a.jtiles = g.p.jtiles; a.jt_per_split = g.p.jt_per_split;
+    const dim3 grid(g.p.nsplit, g.p.tilesS, 3 * g.p.tilesL);
+    if (gauss_tile64(Cs))
+        hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 2, 2, CONV_JT, 2>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 4, 1, CONV_JT, 2>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_unpack_gauss_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work, g.prod_stride,
+                       g.p.nsplit, g.p.SpPad, g.p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
     return idv_launch_status();
 }
 

@@ -17,6 +17,12 @@ struct WgradArgs {
     int SpPad, LpPad;
     int jtiles;          // ceil(J / WG_JT)
     int jt_per_split;
+    // three-product (Gauss) form of the complex weight gradient (wgrad.hip): nprod = 3 independent contractions in one launch,
+    // blockIdx.z = product * tilesL + L tile; product p reads (Sx[p], Lx[p]) and writes part + p * prod_stride
+    int nprod, tilesL;
+    const float* Sx[3];
+    const float* Lx[3];
+    long long prod_stride;
 };
 
 struct Plan { int tilesS, tilesL, nsplit, jtiles, jt_per_split, SpPad, LpPad; };

@@ -865,6 +865,7 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
 _WORK = {}
 WGRAD_BF16_CFG = -96     # ... of wgrad_bf16_kernel + its unpack (bf16x3 training mode)
 WGRAD_BF16 = os.environ.get("IDV_WGRAD_BF16", "1") != "0"
+WGRAD_GAUSS_CFG = -95    # ... of the three-product fp32 weight gradient (wgrad_combine + wgrad_kernel x 3 products + unpack)
 WGRAD_CFG = -97          # LAUNCH_LOG id of the conv weight-gradient kernel (wgrad_kernel<5, 2, 1, 1, 4, 1, 16, 2> + its unpack)
 
 
@@ -884,17 +885,24 @@ def cconv_wgrad(x: Planar, ci_off: int, dy: Planar, cout: int, cin_total: int, t
     # bf16x3 training mode: the wide layers (>= 32 planes on both sides) on the split-bf16 MFMA kernel; the one-channel
     # ends (a handful of planes against a 128 x 32 plane tile) stay on the exact-fp32 kernel
     bf16 = PRECISION == "bf16x3" and WGRAD_BF16 and 2 * cs >= 32 and 2 * cl >= 32
-    n = int(_ll_fn("idv_cconv_wgrad_bf16_work_floats" if bf16 else "idv_cconv_wgrad_work_floats")(i(cs), i(cl), i(x.B), i(x.Tp)))
+    # exact fp32 with three real contractions per complex channel pair (Gauss, csrc/wgrad.hip) where both sides are wide enough
+    gauss = not bf16 and bool(L.lib().idv_cconv_wgrad_gauss_supported(i(cs), i(cl)))
+    if gauss:
+        n = int(_ll_fn("idv_cconv_wgrad_gauss_work_floats")(i(x.C), i(cout), i(1 if transposed else 0), i(x.F), i(x.B), i(x.Tp),
+                                                            i(x.Jp), i(dy.Jp)))
+    else:
+        n = int(_ll_fn("idv_cconv_wgrad_bf16_work_floats" if bf16 else "idv_cconv_wgrad_work_floats")(i(cs), i(cl), i(x.B), i(x.Tp)))
     work = _scratch(n, x.buf.device)
     if LAUNCH_LOG is not None:
         macs = 4 * x.C * cout * 10 * x.B * x.T * (x.F if transposed else dy.F)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    call("idv_cconv2d_bwd_weight_bf16x3" if bf16 else "idv_cconv2d_bwd_weight", x.ptr(), i(x.C), i(ci_off), dy.ptr(), i(cout), i(cin_total), i(1 if transposed else 0),
+    call("idv_cconv2d_bwd_weight_bf16x3" if bf16 else ("idv_cconv2d_bwd_weight_gauss" if gauss else "idv_cconv2d_bwd_weight"),
+         x.ptr(), i(x.C), i(ci_off), dy.ptr(), i(cout), i(cin_total), i(1 if transposed else 0),
          i(tshift), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(dy.Jp), p(work), ll(work.numel()), p(dw_re), p(dw_im), stream_ptr())
     if LAUNCH_LOG is not None:
         ev1.record()
-        LAUNCH_LOG.append((WGRAD_BF16_CFG if bf16 else WGRAD_CFG, macs, ev0, ev1))
+        LAUNCH_LOG.append((WGRAD_BF16_CFG if bf16 else (WGRAD_GAUSS_CFG if gauss else WGRAD_CFG), macs, ev0, ev1))
 
 
 def cconv_bias_grad(dy: Planar):

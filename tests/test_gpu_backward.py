@@ -120,6 +120,45 @@ def test_wgrad_bf16_offsets_beyond_2_gib(ops):
         assert float((a - b).norm() / a.norm()) < 1e-4
 
 
+@pytest.mark.parametrize("transposed,cx,cout,cin_total,ci_off,F,T,B", [
+    (False, 32, 32, 32, 0, 33, 40, 3),        # conv, 64 x 64 tiles (S side = Cout <= 64)
+    (False, 96, 160, 96, 0, 17, 29, 2),       # conv, 128 x 32 tiles, ragged S and L tiles
+    (True, 64, 48, 160, 96, 9, 35, 3),        # transposed conv, the skip half of the weight (ci_off > 0)
+    (True, 160, 32, 160, 0, 5, 130, 2),       # transposed conv, S side = Cx > 64
+])
+def test_wgrad_gauss_matches_four_product_kernel(ops, transposed, cx, cout, cin_total, ci_off, F, T, B):
+    """The three-product (Gauss) weight gradient (idv_cconv2d_bwd_weight_gauss) against the four-product contraction
+    (idv_cconv2d_bwd_weight), itself checked against float64 autograd in test_conv_block_grads: same fp32 operands, different
+    association -> 2e-5 relative per tensor."""
+    L = ops.L
+    g = torch.Generator(device="cuda").manual_seed(11)
+    Fo = 2 * F - 1 if transposed else (F - 1) // 2 + 1
+    x = ops.Planar.empty(cx, F, B, T, T + 1, "cuda")
+    dy = ops.Planar.empty(cout, Fo, B, T, T + 1, "cuda")
+    for t in (x, dy):
+        t.buf.normal_(generator=g)
+        t.planes()[..., 0] = 0.0                                   # guard columns
+    shape = (cin_total, cout, 5, 2) if transposed else (cout, cin_total, 5, 2)
+    cs, cl = (cx, cout) if transposed else (cout, cx)
+    assert L.lib().idv_cconv_wgrad_gauss_supported(L.i(cs), L.i(cl))
+    outs = []
+    for name, sizer, sargs in (("idv_cconv2d_bwd_weight", "idv_cconv_wgrad_work_floats", (L.i(cs), L.i(cl), L.i(B), L.i(x.Tp))),
+                               ("idv_cconv2d_bwd_weight_gauss", "idv_cconv_wgrad_gauss_work_floats",
+                                (L.i(cx), L.i(cout), L.i(int(transposed)), L.i(F), L.i(B), L.i(x.Tp), L.i(x.Jp), L.i(dy.Jp)))):
+        n = int(ops._ll_fn(sizer)(*sargs))
+        work = torch.empty(n, device="cuda")
+        dwr = torch.full(shape, 7.0, device="cuda")              # rows outside [ci_off, ci_off + cx) must stay untouched
+        dwi = torch.full(shape, 7.0, device="cuda")
+        L.call(name, x.ptr(), L.i(cx), L.i(ci_off), dy.ptr(), L.i(cout), L.i(cin_total), L.i(int(transposed)), L.i(-1), L.i(F), L.i(B),
+               L.i(x.Tp), L.i(x.Jp), L.i(dy.Jp), L.p(work), L.ll(n), L.p(dwr), L.p(dwi), L.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((dwr.cpu().double(), dwi.cpu().double()))
+    for a, b in zip(outs[0], outs[1]):
+        assert float((a - b).norm() / a.norm()) < 2e-5
+    sl = outs[1][0][ci_off:ci_off + cx] if transposed else outs[1][0][:, ci_off:ci_off + cx]
+    assert float((sl - 7.0).abs().min()) > 0 and float((outs[1][0] == 7.0).sum()) == outs[1][0].numel() - sl.numel()
+
+
 def _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, ftol, gtol):
     g = torch.Generator().manual_seed(3)
     dev = "cuda"
