@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
         prod = tl / a.tilesL;
         tl -= prod * a.tilesL;
     }
-    const float* __restrict__ Sg = a.nprod > 1 ? a.Sx[prod] : a.S;
-    const float* __restrict__ Lg = a.nprod > 1 ? a.Lx[prod] : a.L;
+    const float* __restrict__ Sg = prod == 0 ? a.S : (prod == 1 ? a.S1 : a.S2);
+    const float* __restrict__ Lg = prod == 0 ? a.L : (prod == 1 ? a.L1 : a.L2);
     const int sp0 = ts * MS, lp0 = tl * ML;
     const int jt0 = split * a.jt_per_split;
     int jt1 = jt0 + a.jt_per_split;
@@ -573,10 +573,9 @@ extern "C" int idv_cconv2d_bwd_weight_gauss(const float* x, int Cx, int ci_off, 
     const float* L_im = L + (size_t)Cl * a.Fl * a.JpL;
     hipLaunchKernelGGL(wgrad_combine_kernel, dim3(grid_for(ns4)), dim3(256), 0, st, S, S_im, ns4, s_sum, (float*)nullptr);
     hipLaunchKernelGGL(wgrad_combine_kernel, dim3(grid_for(nl4)), dim3(256), 0, st, L, L_im, nl4, l_sum, l_dif);
-    a.S = S; a.L = L;
-    a.Sx[0] = s_sum; a.Lx[0] = L;        // k1 = (p + q) u
-    a.Sx[1] = S;     a.Lx[1] = l_sum;    // k2 = p (u + v)
-    a.Sx[2] = S_im;  a.Lx[2] = l_dif;    // k3 = q (u - v)
+    a.S = s_sum; a.L = L;         // k1 = (p + q) u
+    a.S1 = S;    a.L1 = l_sum;    // k2 = p (u + v)
+    a.S2 = S_im; a.L2 = l_dif;    // k3 = q (u - v)
     a.nprod = 3; a.tilesL = g.p.tilesL; a.prod_stride = g.prod_stride;
     a.part = work; a.SpPad = g.p.SpPad; a.LpPad = g.p.LpPad; a.jtiles = g.p.jtiles; a.jt_per_split = g.p.jt_per_split;
     const dim3 grid(g.p.nsplit, g.p.tilesS, 3 * g.p.tilesL);

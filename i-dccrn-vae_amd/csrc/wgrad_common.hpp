@@ -19,9 +19,10 @@ struct WgradArgs {
     int jt_per_split;
     // three-product (Gauss) form of the complex weight gradient (wgrad.hip): nprod = 3 independent contractions in one launch,
     // blockIdx.z = product * tilesL + L tile; product p reads (Sx[p], Lx[p]) and writes part + p * prod_stride
+    // (separate scalar fields, selected with ?: -- an array indexed by the product would send the whole by-value argument
+    //  block, and with it every field the main loop reads, through scratch memory: 2.3x slower, measured)
     int nprod, tilesL;
-    const float* Sx[3];
-    const float* Lx[3];
+    const float *S1, *S2, *L1, *L2;      // products 1 and 2 (product 0: S, L)
     long long prod_stride;
 };
 
