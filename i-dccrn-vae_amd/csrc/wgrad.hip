@@ -505,12 +505,10 @@ extern "C" int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const 
 // ---- Gauss form: entry points -----------------------------------------------------------------------------------------------
 namespace {
 const bool WGRAD_GAUSS = [] { const char* e = getenv("IDV_WGRAD_GAUSS"); return !e || e[0] != '0'; }();
-// S tile of 128 planes x L tile of 32, or 64 x 64 where the S side has at most 64 planes
-inline bool gauss_tile64(int Cs) { return Cs <= 64; }
 struct GaussPlan { Plan p; long long prod_stride, part_floats, s_sum, l_each; };
 inline GaussPlan gauss_plan(int Cs, int Cl, int Fs, int Fl, int J, int JpS, int JpL) {
     GaussPlan g;
-    g.p = gauss_tile64(Cs) ? make_plan(Cs, Cl, J, 64, 64, CONV_JT) : make_plan(Cs, Cl, J, CONV_MS, CONV_ML, CONV_JT);
+    g.p = make_plan(Cs, Cl, J, CONV_MS, CONV_ML, CONV_JT);
     // make_plan aims its workgroup count at ONE contraction; there are three in the launch
     g.prod_stride = (long long)g.p.nsplit * 10 * g.p.SpPad * g.p.LpPad;
     g.part_floats = 3 * g.prod_stride;
@@ -520,8 +518,10 @@ inline GaussPlan gauss_plan(int Cs, int Cl, int Fs, int Fl, int J, int JpS, int 
 }
 }  // namespace
 
-// 1 if idv_cconv2d_bwd_weight_gauss serves the layer (>= 32 complex channels on both sides; IDV_WGRAD_GAUSS=0 turns it off)
-extern "C" int idv_cconv_wgrad_gauss_supported(int Cs, int Cl) { return WGRAD_GAUSS && Cs >= 32 && Cl >= 32; }
+// 1 if idv_cconv2d_bwd_weight_gauss serves the layer (IDV_WGRAD_GAUSS=0 turns it off)
+// (Cs >= 128: the S tile of the contraction kernel is 128 planes; with the real and imaginary planes no longer stacked a
+//  64-channel S side would leave half of it empty, and 3 products at 50 % lose against 4 at 100 %)
+extern "C" int idv_cconv_wgrad_gauss_supported(int Cs, int Cl) { return WGRAD_GAUSS && Cs >= 128 && Cl >= 32; }
 
 // work floats of idv_cconv2d_bwd_weight_gauss: split-K partials of the three products + the combined planes (p + q | u + v | u - v)
 extern "C" long long idv_cconv_wgrad_gauss_work_floats(int Cx, int Cout, int transposed, int Fin, int B, int Tp, int Jp_x, int Jp_dy) {
@@ -579,10 +579,7 @@ extern "C" int idv_cconv2d_bwd_weight_gauss(const float* x, int Cx, int ci_off, 
     a.nprod = 3; a.tilesL = g.p.tilesL; a.prod_stride = g.prod_stride;
     a.part = work; a.SpPad = g.p.SpPad; a.LpPad = g.p.LpPad; a.jtiles = g.p.jtiles; a.jt_per_split = g.p.jt_per_split;
     const dim3 grid(g.p.nsplit, g.p.tilesS, 3 * g.p.tilesL);
-    if (gauss_tile64(Cs))
-        hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 2, 2, CONV_JT, 2>), grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 4, 1, CONV_JT, 2>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 4, 1, CONV_JT, 2>), grid, dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_unpack_gauss_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work, g.prod_stride,
                        g.p.nsplit, g.p.SpPad, g.p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
     return idv_launch_status();

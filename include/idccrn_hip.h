@@ -390,8 +390,9 @@ int idv_cconv2d_bwd_weight_bf16x3(const float* x, int Cx, int ci_off, const floa
 /* idv_cconv2d_bwd_weight with THREE real contractions per complex channel pair (Gauss: k1 = (p + q) u, k2 = p (u + v),
  * k3 = q (u - v); dWr = k1 - k3, dWi = +-(k1 - k2) with (p, q) / (u, v) the real / imaginary planes of the two operands): the same
  * weight gradient (reference: torch.autograd of nn.Conv2d / nn.ConvTranspose2d, model/complex_progress.py:8-36, :222-279) with 25 %
- * fewer multiplications; arguments as idv_cconv2d_bwd_weight.  idv_cconv_wgrad_gauss_supported(Cs, Cl): both sides >= 32 complex
- * channels (Cs / Cl = the S / L side: conv (Cout, Cx), transposed conv (Cx, Cout)); work: idv_cconv_wgrad_gauss_work_floats. */
+ * fewer multiplications; arguments as idv_cconv2d_bwd_weight.  idv_cconv_wgrad_gauss_supported(Cs, Cl): Cs >= 128 and Cl >= 32
+ * complex channels (Cs / Cl = the S / L side: conv (Cout, Cx), transposed conv (Cx, Cout); a narrower S side would leave the
+ * kernel's 128-plane tile half empty); work: idv_cconv_wgrad_gauss_work_floats. */
 int idv_cconv_wgrad_gauss_supported(int Cs, int Cl);
 long long idv_cconv_wgrad_gauss_work_floats(int Cx, int Cout, int transposed, int Fin, int B, int Tp, int Jp_x, int Jp_dy);
 int idv_cconv2d_bwd_weight_gauss(const float* x, int Cx, int ci_off, const float* dy, int Cout, int Cin_total, int transposed,

@@ -121,10 +121,10 @@ def test_wgrad_bf16_offsets_beyond_2_gib(ops):
 
 
 @pytest.mark.parametrize("transposed,cx,cout,cin_total,ci_off,F,T,B", [
-    (False, 32, 32, 32, 0, 33, 40, 3),        # conv, 64 x 64 tiles (S side = Cout <= 64)
-    (False, 96, 160, 96, 0, 17, 29, 2),       # conv, 128 x 32 tiles, ragged S and L tiles
-    (True, 64, 48, 160, 96, 9, 35, 3),        # transposed conv, the skip half of the weight (ci_off > 0)
-    (True, 160, 32, 160, 0, 5, 130, 2),       # transposed conv, S side = Cx > 64
+    (False, 32, 128, 32, 0, 33, 40, 3),       # conv, one S tile
+    (False, 96, 160, 96, 0, 17, 29, 2),       # conv, ragged S and L tiles
+    (True, 128, 48, 224, 96, 9, 35, 3),       # transposed conv, the skip half of the weight (ci_off > 0)
+    (True, 160, 32, 160, 0, 5, 130, 2),       # transposed conv, ragged S tile
 ])
 def test_wgrad_gauss_matches_four_product_kernel(ops, transposed, cx, cout, cin_total, ci_off, F, T, B):
     """The three-product (Gauss) weight gradient (idv_cconv2d_bwd_weight_gauss) against the four-product contraction
