@@ -248,25 +248,21 @@ __global__ void wgrad_unpack_conv_kernel(const float* __restrict__ part, int nsp
     }
 }
 
-// ---- three-product (Gauss) form of the complex weight gradient -------------------------------------------------------------
+// ---- three-product (Gauss / Karatsuba) form of the complex weight gradient -------------------------------------------------
 // With (p, q) the real / imaginary planes of an S channel and (u, v) those of an L channel, the complex weight gradient needs
 //   dWr = p u + q v,   dWi = q u - p v  (conv; transposed conv: p v - q u)      -- four real contractions per channel pair.
-// Gauss:  k1 = (p + q) u,  k2 = p (u + v),  k3 = q (u - v):   dWr = k1 - k3,  dWi = k1 - k2 (conv) / k2 - k1 (transposed):
-// three contractions, each between Cs x Cl REAL planes -- the wgrad_kernel as it is, launched once with three (S, L) operand
-// pairs.  The combined planes (p + q), (u + v), (u - v) are written once per call by an elementwise pass (HBM-bound, ~3 % of
-// the contraction's time); this kernel sums the split-K partials of the three products and applies the signs.
-__global__ void wgrad_combine_kernel(const float* __restrict__ re, const float* __restrict__ im, long long n4,
-                                     float* __restrict__ sum, float* __restrict__ diff) {
+// Three suffice:  P1 = p u,  P2 = q v,  P3 = (p - q)(u + v):   dWr = P1 + P2,  dWi = P1 - P2 - P3 (conv) / P3 + P2 - P1 (transposed)
+// -- each a contraction between Cs x Cl REAL planes: the wgrad_kernel as it is, launched once with three (S, L) operand pairs.
+// This variant needs ONE combined plane set per side, (p - q) and (u + v), written once per call by an elementwise pass
+// (HBM-bound); the unpack kernel sums the split-K partials of the three products and applies the signs.
+__global__ void wgrad_combine_kernel(const float* __restrict__ re, const float* __restrict__ im, long long n4, float sign,
+                                     float* __restrict__ out) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const f32x4 a = ((const f32x4*)re)[i], b = ((const f32x4*)im)[i];
-        f32x4 s4, d4;
+        f32x4 o;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            s4[c] = a[c] + b[c];
-            d4[c] = a[c] - b[c];
-        }
-        ((f32x4*)sum)[i] = s4;
-        if (diff) ((f32x4*)diff)[i] = d4;
+        for (int c = 0; c < 4; ++c) o[c] = a[c] + sign * b[c];
+        ((f32x4*)out)[i] = o;
     }
 }
 
@@ -280,15 +276,15 @@ __global__ void wgrad_unpack_gauss_kernel(const float* __restrict__ part, long l
         const int lc = (int)(idx % Cl);
         const int sc = (int)((idx / Cl) % Cs);
         const int tap = (int)(idx / ((long long)Cl * Cs));
-        double k1 = 0, k2 = 0, k3 = 0;
+        double p1 = 0, p2 = 0, p3 = 0;
         for (int sidx = 0; sidx < nsplit; ++sidx) {
             const float* P = part + ((size_t)sidx * 10 + tap) * plane + (size_t)sc * LpPad + lc;
-            k1 += P[0];
-            k2 += P[prod_stride];
-            k3 += P[2 * prod_stride];
+            p1 += P[0];
+            p2 += P[prod_stride];
+            p3 += P[2 * prod_stride];
         }
-        const double dwr = k1 - k3;
-        const double dwi = transposed ? (k2 - k1) : (k1 - k2);
+        const double dwr = p1 + p2;
+        const double dwi = transposed ? (p3 + p2 - p1) : (p1 - p2 - p3);
         const int co = transposed ? lc : sc, ci = ci_off + (transposed ? sc : lc);
         const size_t o = transposed ? (((size_t)ci * Cout + co) * 10 + tap) : (((size_t)co * Cin_total + ci) * 10 + tap);
         dw_re[o] = (float)dwr;
@@ -505,15 +501,15 @@ extern "C" int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const 
 // ---- Gauss form: entry points -----------------------------------------------------------------------------------------------
 namespace {
 const bool WGRAD_GAUSS = [] { const char* e = getenv("IDV_WGRAD_GAUSS"); return !e || e[0] != '0'; }();
-struct GaussPlan { Plan p; long long prod_stride, part_floats, s_sum, l_each; };
+struct GaussPlan { Plan p; long long prod_stride, part_floats, s_comb, l_comb; };
 inline GaussPlan gauss_plan(int Cs, int Cl, int Fs, int Fl, int J, int JpS, int JpL) {
     GaussPlan g;
     g.p = make_plan(Cs, Cl, J, CONV_MS, CONV_ML, CONV_JT);
     // make_plan aims its workgroup count at ONE contraction; there are three in the launch
     g.prod_stride = (long long)g.p.nsplit * 10 * g.p.SpPad * g.p.LpPad;
     g.part_floats = 3 * g.prod_stride;
-    g.s_sum = ((long long)Cs * Fs * JpS + 63) / 64 * 64;
-    g.l_each = ((long long)Cl * Fl * JpL + 63) / 64 * 64;
+    g.s_comb = ((long long)Cs * Fs * JpS + 63) / 64 * 64;
+    g.l_comb = ((long long)Cl * Fl * JpL + 63) / 64 * 64;
     return g;
 }
 }  // namespace
@@ -523,14 +519,14 @@ inline GaussPlan gauss_plan(int Cs, int Cl, int Fs, int Fl, int J, int JpS, int 
 //  64-channel S side would leave half of it empty, and 3 products at 50 % lose against 4 at 100 %)
 extern "C" int idv_cconv_wgrad_gauss_supported(int Cs, int Cl) { return WGRAD_GAUSS && Cs >= 128 && Cl >= 32; }
 
-// work floats of idv_cconv2d_bwd_weight_gauss: split-K partials of the three products + the combined planes (p + q | u + v | u - v)
+// work floats of idv_cconv2d_bwd_weight_gauss: split-K partials of the three products + the combined planes (p - q | u + v)
 extern "C" long long idv_cconv_wgrad_gauss_work_floats(int Cx, int Cout, int transposed, int Fin, int B, int Tp, int Jp_x, int Jp_dy) {
     if (Cx <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 0) return -1;
     const int Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
     const int Cs = transposed ? Cx : Cout, Cl = transposed ? Cout : Cx;
     const int Fs = transposed ? Fin : Fout, Fl = transposed ? Fout : Fin;
     const GaussPlan g = gauss_plan(Cs, Cl, Fs, Fl, B * Tp, transposed ? Jp_x : Jp_dy, transposed ? Jp_dy : Jp_x);
-    return g.part_floats + g.s_sum + 2 * g.l_each;
+    return g.part_floats + g.s_comb + g.l_comb;
 }
 
 // idv_cconv2d_bwd_weight with three real contractions per complex channel pair instead of four (same arguments, same result up
@@ -563,19 +559,18 @@ extern "C" int idv_cconv2d_bwd_weight_gauss(const float* x, int Cx, int ci_off, 
     a.J = B * Tp;
     a.Sp = Cs; a.Lp = Cl;
     const GaussPlan g = gauss_plan(Cs, Cl, a.Fs, a.Fl, a.J, a.JpS, a.JpL);
-    if (g.part_floats + g.s_sum + 2 * g.l_each > work_floats) return IDV_EINVAL;
+    if (g.part_floats + g.s_comb + g.l_comb > work_floats) return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    float* s_sum = work + g.part_floats;
-    float* l_sum = s_sum + g.s_sum;
-    float* l_dif = l_sum + g.l_each;
+    float* s_dif = work + g.part_floats;
+    float* l_sum = s_dif + g.s_comb;
     const long long ns4 = (long long)Cs * a.Fs * a.JpS / 4, nl4 = (long long)Cl * a.Fl * a.JpL / 4;
     const float* S_im = S + (size_t)Cs * a.Fs * a.JpS;
     const float* L_im = L + (size_t)Cl * a.Fl * a.JpL;
-    hipLaunchKernelGGL(wgrad_combine_kernel, dim3(grid_for(ns4)), dim3(256), 0, st, S, S_im, ns4, s_sum, (float*)nullptr);
-    hipLaunchKernelGGL(wgrad_combine_kernel, dim3(grid_for(nl4)), dim3(256), 0, st, L, L_im, nl4, l_sum, l_dif);
-    a.S = s_sum; a.L = L;         // k1 = (p + q) u
-    a.S1 = S;    a.L1 = l_sum;    // k2 = p (u + v)
-    a.S2 = S_im; a.L2 = l_dif;    // k3 = q (u - v)
+    hipLaunchKernelGGL(wgrad_combine_kernel, dim3(grid_for(ns4)), dim3(256), 0, st, S, S_im, ns4, -1.0f, s_dif);
+    hipLaunchKernelGGL(wgrad_combine_kernel, dim3(grid_for(nl4)), dim3(256), 0, st, L, L_im, nl4, 1.0f, l_sum);
+    a.S = S;      a.L = L;        // P1 = p u
+    a.S1 = S_im;  a.L1 = L_im;    // P2 = q v
+    a.S2 = s_dif; a.L2 = l_sum;   // P3 = (p - q)(u + v)
     a.nprod = 3; a.tilesL = g.p.tilesL; a.prod_stride = g.prod_stride;
     a.part = work; a.SpPad = g.p.SpPad; a.LpPad = g.p.LpPad; a.jtiles = g.p.jtiles; a.jt_per_split = g.p.jt_per_split;
     const dim3 grid(g.p.nsplit, g.p.tilesS, 3 * g.p.tilesL);

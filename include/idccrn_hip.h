@@ -387,8 +387,8 @@ long long idv_cconv_wgrad_bf16_work_floats(int Cs, int Cl, int B, int Tp);
 int idv_cconv2d_bwd_weight_bf16x3(const float* x, int Cx, int ci_off, const float* dy, int Cout, int Cin_total, int transposed,
                                   int tshift, int Fin, int B, int Tp, int Jp_x, int Jp_dy, float* work, long long work_floats,
                                   float* dw_re, float* dw_im, void* stream);
-/* idv_cconv2d_bwd_weight with THREE real contractions per complex channel pair (Gauss: k1 = (p + q) u, k2 = p (u + v),
- * k3 = q (u - v); dWr = k1 - k3, dWi = +-(k1 - k2) with (p, q) / (u, v) the real / imaginary planes of the two operands): the same
+/* idv_cconv2d_bwd_weight with THREE real contractions per complex channel pair (Gauss / Karatsuba: P1 = p u, P2 = q v,
+ * P3 = (p - q)(u + v); dWr = P1 + P2, dWi = +-(P1 - P2 - P3) with (p, q) / (u, v) the real / imaginary planes of the two operands): the same
  * weight gradient (reference: torch.autograd of nn.Conv2d / nn.ConvTranspose2d, model/complex_progress.py:8-36, :222-279) with 25 %
  * fewer multiplications; arguments as idv_cconv2d_bwd_weight.  idv_cconv_wgrad_gauss_supported(Cs, Cl): Cs >= 128 and Cl >= 32
  * complex channels (Cs / Cl = the S / L side: conv (Cout, Cx), transposed conv (Cx, Cout); a narrower S side would leave the
