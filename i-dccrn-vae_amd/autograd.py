@@ -58,6 +58,33 @@ class ConvBlockFn(torch.autograd.Function):
         cin_used = x.C if zero_skip else None
         cout = conv.out_channel
         dev = xbuf.device
+        div = meta.get("skip_div", 1)
+        if div > 1:
+            # repeated skips (pvae_module.py:2563-2567), fp32: the skip half of the (linear) transposed conv runs ONCE per
+            # utterance and is added to each sample's latent half by the epilogue (conv_block only takes this path when
+            # skip_once_ok); backward sums dy over the samples first and runs the skip half's data / weight gradient at batch B
+            re, im = conv._re, conv._im
+            g_skip = conv._cache_gauss_skip.get((re.weight, im.weight), x.C, lambda: ops.pack_cconv_gauss_skip_part(
+                re.weight.detach(), im.weight.detach(), x.C))
+            y_skip = ops.cconv2d(skip, None, None, cout, transposed=True, causal=True, gauss=g_skip)
+            g_main = conv.packed_gauss(None, x.C)
+            stats = torch.zeros(cout, 5, dtype=torch.float64, device=dev) if bn is not None else None
+            y = ops.cconv2d(x, None, None, cout, transposed=True, causal=True, stats=stats, gauss=g_main, addend=y_skip,
+                            addend_div=div)
+            if bn is not None:
+                first = bool(bn.init_flag)
+                moments, fold = ops.cbn_finalize(stats, float(y.B) * y.F * y.T, bn, first, bn.momentum)
+                bn._stats_gen += 1
+                if first and not bn.dis_cbn:
+                    bn.init_flag = False
+                z = ops.cbn_apply_to(y, fold, slope)
+                ctx.save_for_backward(xbuf, skipbuf, w_re, w_im, y.buf, fold, moments, g_rr, g_ri, g_ii, slope)
+            else:
+                z = y
+                ctx.save_for_backward(xbuf, skipbuf, w_re, w_im, None, None, None, None, None, None, None)
+            ctx.meta = meta
+            ctx.zgeom = _geom(z)
+            return z.buf
         # bf16x3 training mode: forward and data gradient on the split-bf16 MFMA kernels where the shape allows
         # (every block but the one-channel ends); weight gradients stay on the fp32 MFMA
         wbf = None
@@ -132,13 +159,20 @@ class ConvBlockFn(torch.autograd.Function):
             else:
                 db_re, db_im = ops.cconv_bias_grad(dy)
         cin_total = w_re.shape[0] if tr else w_re.shape[1]
+        div = meta.get("skip_div", 1)
+        dy_sum = None
+        if div > 1 and (need_w or (ctx.needs_input_grad[2] and skip is not None)):
+            # sum of dy over the num_samples copies of each utterance: what the skip half's gradients contract with
+            dy_sum = Planar.empty(dy.C, dy.F, skip.B, dy.T, dy.Tp, dy.buf.device)
+            call("idv_repeat_batch_bwd", dy.ptr(), i(div), i(2 * dy.C * dy.F), i(skip.B), i(dy.Tp), i(dy.Jp), i(dy_sum.Jp),
+                 dy_sum.ptr(), stream_ptr())
         if need_w:
             used = x.C + (skip.C if skip is not None else 0)
             mk = torch.zeros_like if used < cin_total else torch.empty_like
             dw_re, dw_im = mk(w_re), mk(w_im)
             ops.cconv_wgrad(x, 0, dy, cout, cin_total, tr, True, dw_re, dw_im)
             if skip is not None:
-                ops.cconv_wgrad(skip, x.C, dy, cout, cin_total, tr, True, dw_re, dw_im)
+                ops.cconv_wgrad(skip, x.C, dy_sum if div > 1 else dy, cout, cin_total, tr, True, dw_re, dw_im)
         # data gradients: the adjoint operator with conjugate-transposed weights
         dx = dskip = None
         need_x, need_s = ctx.needs_input_grad[1], ctx.needs_input_grad[2] and skip is not None
@@ -154,7 +188,10 @@ class ConvBlockFn(torch.autograd.Function):
                     dx = _dgrad(dy, w_re, w_im, x.C, cout, True, dy_img)
                 if need_s:
                     wr, wi = w_re.reshape(-1)[x.C * per:], w_im.reshape(-1)[x.C * per:]
-                    dskip = _dgrad(dy, wr, wi, skip.C, cout, True, dy_img)
+                    if div > 1:
+                        dskip = _dgrad(dy_sum, wr, wi, skip.C, cout, True, None)
+                    else:
+                        dskip = _dgrad(dy, wr, wi, skip.C, cout, True, dy_img)
         return (None, _fit(dx, xbuf) if dx is not None else None, _fit(dskip, skipbuf) if dskip is not None else None,
                 dw_re, dw_im, db_re, db_im) + grads_bn
 
@@ -199,10 +236,20 @@ def _dy_image(dy: Planar, cin_adj: int):
     return ops.to_image(dy) if _dy_image_wanted(cin_adj) else None
 
 
-def conv_block(conv, bn, prelu_weight, x: Planar, skip: Optional[Planar], zero_skip: bool) -> Planar:
+def skip_once_ok(conv, x: Planar, skip: Optional[Planar], skip_div: int) -> bool:
+    """Can the block run the skip half of its transposed conv once per utterance (fp32, three-product kernel on both halves)?"""
+    return (skip is not None and skip_div > 1 and ops.PRECISION == "fp32" and ops.SKIP_ONCE and conv._transposed and conv._causal
+            and x.B == skip.B * skip_div and ops.gauss_supported(x.C, 0, conv.out_channel)
+            and ops.gauss_supported(skip.C, 0, conv.out_channel))
+
+
+def conv_block(conv, bn, prelu_weight, x: Planar, skip: Optional[Planar], zero_skip: bool, skip_div: int = 1) -> Planar:
+    """skip_div > 1: `skip` holds B utterances, x holds B * skip_div samples (callers check skip_once_ok; otherwise they
+    materialise the repeat with repeat_batch and pass skip_div = 1)."""
     re, im = conv._re, conv._im
     conv._check_supported()
-    meta = dict(conv=conv, bn=bn, x=_geom(x), skip=_geom(skip) if skip is not None else None, zero_skip=zero_skip)
+    meta = dict(conv=conv, bn=bn, x=_geom(x), skip=_geom(skip) if skip is not None else None, zero_skip=zero_skip,
+                skip_div=skip_div)
     bnp = (bn.gamma_rr, bn.gamma_ri, bn.gamma_ii, bn.beta_r, bn.beta_i) if bn is not None else (None,) * 5
     cout = conv.out_channel
     Fout = 2 * x.F - 1 if conv._transposed else (x.F - 1) // 2 + 1

@@ -536,7 +536,7 @@ extern "C" int idv_cconv2d_gauss_fwd(const float* x0, int C0, const float* x1, i
                                      int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out,
                                      const float* addend, int addend_div, int addend_Jp, void* stream) {
     if (!x0 || !wfrag || !epi || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
-    if (addend && (addend_div < 1 || B % addend_div || addend_Jp < (B / addend_div) * Tp || stats)) return IDV_EINVAL;
+    if (addend && (addend_div < 1 || B % addend_div || addend_Jp < (B / addend_div) * Tp)) return IDV_EINVAL;
     if (C1 > 0 && (!x1 || x1_div < 1)) return IDV_EINVAL;
     if (tshift != 0 && tshift != -1) return IDV_EINVAL;
     if (!idv_cconv_gauss_supported(C0, C1, Cout)) return IDV_EINVAL;

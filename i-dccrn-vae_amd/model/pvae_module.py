@@ -98,6 +98,8 @@ class _Block(nn.Module):
                 raise RuntimeError("split images are an eval-mode format")
             div = kw.get("skip_div", 1)
             if skip is not None and div > 1:
+                if AG.skip_once_ok(conv, x, skip, div):      # fp32: skip half of the conv once per utterance
+                    return AG.conv_block(conv, self.bn, self.prelu.weight, x, skip, kw.get("zero_skip", False), skip_div=div)
                 skip = AG.repeat_batch(skip, div)
             return AG.conv_block(conv, self.bn, self.prelu.weight, x, skip, kw.get("zero_skip", False))
         if train:

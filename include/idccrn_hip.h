@@ -107,7 +107,7 @@ int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, i
  * eval-mode ComplexBatchNormal (fold, complex_progress.py:161-209) is a real 2x2 map, so it cannot be folded into the three
  * weight planes and is applied by the epilogue when has_fold != 0 (then PReLU, pvae_module.py:58,82).  conj != 0 packs the
  * adjoint (data-gradient) operator: W_i negated, the caller passes the swapped channel roles as for idv_pack_cconv_adjoint.
- * addend (or NULL; eval only): planar [2][Cout][Fout][addend_Jp] holding B / addend_div utterances, added to the contraction
+ * addend (or NULL): planar [2][Cout][Fout][addend_Jp] holding B / addend_div utterances, added to the contraction
  * before bias / BN / PReLU: output utterance b takes addend utterance b / addend_div.  The convolution is linear in its input
  * channels, so for the repeated skips of pvae_module.py:2563-2567 the skip half is computed ONCE per utterance (a call with
  * x0 = skip, the skip rows of the weight, no bias) and added to each of its num_samples latent halves.
