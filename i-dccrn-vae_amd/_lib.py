@@ -11,7 +11,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libidccrn_hip.so")
+# IDV_LIB_PATH: another build of the same library (A/B measurements of a kernel variant on one box); default: the in-tree build
+LIB_PATH = os.environ.get("IDV_LIB_PATH") or os.path.join(_HERE, "csrc", "libidccrn_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "idccrn_hip.h")
 
 _lib = None
