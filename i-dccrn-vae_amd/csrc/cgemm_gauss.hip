@@ -59,8 +59,8 @@ struct GaussGeom {
 // the last unit and the next chunk's first fragments are read during the last unit's MFMAs -- nothing waits at the chunk
 // boundary.  Three buffers because a wave that has passed barrier(c-1) may write chunk c+1's patch while a slower wave still
 // reads chunk c-1's in its last unit: they must be different buffers.
-template <int MODE, int WM, int WN, int FO_T, int JC_W, int CIK, bool STATS, bool VEC, int NBUF>
-__global__ __launch_bounds__(WM* WN * 64, 1) void cgemm_gauss_kernel(const GaussArgs a) {
+template <int MODE, int WM, int WN, int FO_T, int JC_W, int CIK, bool STATS, bool VEC, int NBUF, int OCC = 1>
+__global__ __launch_bounds__(WM* WN * 64, OCC) void cgemm_gauss_kernel(const GaussArgs a) {
     using G = GaussGeom<MODE, FO_T>;
     constexpr int NT = WM * WN * 64;
     constexpr int KF = 5, FR = G::FR, ROWS = G::ROWS;
@@ -418,12 +418,12 @@ __global__ void pack_cconv_gauss_kernel(const float* __restrict__ w_re, const fl
     }
 }
 
-template <int MODE, int WM, int WN, int FO_T, int JC_W, int CIK, bool STATS, bool VEC>
+template <int MODE, int WM, int WN, int FO_T, int JC_W, int CIK, bool STATS, bool VEC, int OCC = 1>
 int launch_gauss_v(const GaussArgs& a, hipStream_t st) {
     using G = GaussGeom<MODE, FO_T>;
     constexpr int JT = 32 * JC_W * WN;
     constexpr int NE = CIK * 3 * G::FR * (JT + 8);
-    constexpr int NBUF = (3 * NE * sizeof(float) <= 156 * 1024) ? 3 : 2;     // three patch buffers where the LDS holds them
+    constexpr int NBUF = (3 * NE * sizeof(float) * OCC <= 156 * 1024) ? 3 : 2;     // three patch buffers where the LDS holds them
     constexpr size_t smem = NBUF * NE * sizeof(float);
     const int rows = (MODE == IDV_TCONV) ? a.Fin : a.Fout;
     GaussArgs b = a;
@@ -435,7 +435,7 @@ int launch_gauss_v(const GaussArgs& a, hipStream_t st) {
     const long long tiles = (long long)b.jtiles * b.ftiles;
     const long long nblk = b.map_ft ? (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks : ((tiles + 7) / 8) * 8 * b.mblocks;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = cgemm_gauss_kernel<MODE, WM, WN, FO_T, JC_W, CIK, STATS, VEC, NBUF>;
+    auto k = cgemm_gauss_kernel<MODE, WM, WN, FO_T, JC_W, CIK, STATS, VEC, NBUF, OCC>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return IDV_ELAUNCH;
@@ -443,13 +443,13 @@ int launch_gauss_v(const GaussArgs& a, hipStream_t st) {
     return idv_launch_status();
 }
 
-template <int MODE, int WM, int WN, int FO_T, int JC_W, int CIK, bool STATS>
+template <int MODE, int WM, int WN, int FO_T, int JC_W, int CIK, bool STATS, int OCC = 1>
 int launch_gauss(const GaussArgs& a, hipStream_t st) {
     // vector staging: 16-byte aligned rows and the same column mapping for both sources
     const bool vec = (a.Jp % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x0) & 15) == 0) &&
                      (a.C1 == 0 || (a.x1_div == 1 && a.Jp1 == a.Jp && (reinterpret_cast<uintptr_t>(a.x1) & 15) == 0));
-    if (vec) return launch_gauss_v<MODE, WM, WN, FO_T, JC_W, CIK, STATS, true>(a, st);
-    return launch_gauss_v<MODE, WM, WN, FO_T, JC_W, CIK, STATS, false>(a, st);
+    if (vec) return launch_gauss_v<MODE, WM, WN, FO_T, JC_W, CIK, STATS, true, OCC>(a, st);
+    return launch_gauss_v<MODE, WM, WN, FO_T, JC_W, CIK, STATS, false, OCC>(a, st);
 }
 
 inline int waste(int n, int t) { return ((n + t - 1) / t) * t - n; }
@@ -473,7 +473,14 @@ template <bool STATS>
 int launch_cfg(const GaussArgs& a, int transposed, hipStream_t st) {
     const int rows = transposed ? a.Fin : a.Fout;
     switch (gauss_config(transposed, a.Cout, rows)) {
-        case 312212: return launch_gauss<IDV_TCONV, 2, 2, 1, 2, CIK, STATS>(a, st);
+        case 312212: {
+            // experiments (IDV_GAUSS_TCFG): 1 = one co tile x four column groups per workgroup, 2 = two waves per SIMD with
+            // half the column tiles each
+            static const int tcfg = [] { const char* e = getenv("IDV_GAUSS_TCFG"); return e ? atoi(e) : 0; }();
+            if (tcfg == 1 && !STATS) return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
+            if (tcfg == 2 && !STATS) return launch_gauss<IDV_TCONV, 2, 2, 1, 1, CIK, STATS, 2>(a, st);
+            return launch_gauss<IDV_TCONV, 2, 2, 1, 2, CIK, STATS>(a, st);
+        }
         case 311412: return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
         case 302251: return launch_gauss<IDV_CONV, 2, 2, 5, 1, CIK5, STATS>(a, st);
         case 302231: return launch_gauss<IDV_CONV, 2, 2, 3, 1, CIK, STATS>(a, st);
