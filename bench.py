@@ -339,7 +339,7 @@ def kernel_name(cfg_id):
         jt = 32 * int(d[5]) * int(d[3])
         fr = 2 * int(d[4]) + 3 if d[1] == "0" else int(d[4]) + 2
         nbuf = 3 if 3 * cik * 3 * fr * (jt + 8) * 4 <= 156 * 1024 else 2
-        return (f"void (anonymous namespace)::cgemm_gauss_kernel<{d[1]}, {d[2]}, {d[3]}, {d[4]}, {d[5]}, {cik}, false, true, {nbuf}>"
+        return (f"void (anonymous namespace)::cgemm_gauss_kernel<{d[1]}, {d[2]}, {d[3]}, {d[4]}, {d[5]}, {cik}, false, true, {nbuf}, 1>"
                 "((anonymous namespace)::GaussArgs)")
     if cfg_id > 0:
         d = str(cfg_id)

@@ -142,6 +142,17 @@ extern "C" int idv_pw_gemm(const float* x, int K, const float* wfrag, const floa
     a.tshift = 0; a.t_valid = t_valid; a.stats = nullptr; a.ldo = ldo; a.nB = B;
     if (Jp < a.J) return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    // IDV_PW_CFG (experiments): 1 = four column tiles per wave, 2 = four row tiles per wave (rows in whole 256-row blocks only:
+    // the fragment buffer is allocated in 128-row blocks)
+    static const int pwcfg = [] { const char* e = getenv("IDV_PW_CFG"); return e ? atoi(e) : 0; }();
+    if (pwcfg == 1) {
+        if (swap) return launch_cfg<IDV_PW, 2, 2, 2, 1, 4, 8, true, false>(a, st);
+        return launch_cfg<IDV_PW, 2, 2, 2, 1, 4, 8, false, false>(a, st);
+    }
+    if (pwcfg == 2 && a.Mtiles % 8 == 0) {
+        if (swap) return launch_cfg<IDV_PW, 2, 2, 4, 1, 2, 8, true, false>(a, st);
+        return launch_cfg<IDV_PW, 2, 2, 4, 1, 2, 8, false, false>(a, st);
+    }
     if (swap) return launch_cfg<IDV_PW, 2, 2, 2, 1, 2, 8, true, false>(a, st);
     return launch_cfg<IDV_PW, 2, 2, 2, 1, 2, 8, false, false>(a, st);
 }
