@@ -259,3 +259,37 @@ def test_reference_written_checkpoint_loads_and_round_trips(tmp_path):
     assert set(again) == {"epoch", "best_val_loss", "cpt_patience", "loss_log", "model_state_dict", "model_optim_dict",
                           "model_scheduler_dict"}
     assert os.path.basename(ck.save_best_epoch(m, str(tmp_path), "NSVAE", "noisy_encoder")) == "NSVAE_noisy_encoder_best_epoch.pt"
+
+
+def test_bench_self_launch_starts_ranks_as_a_child_and_relays_rank0(monkeypatch, capsys):
+    """`python bench.py --gpus N` without WORLD_SIZE: the process becomes the launcher -- `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a CHILD process (no exec, no torch import in
+    the parent), rank 0's JSON line relayed on stdout, everything else on stderr, the child's exit code returned."""
+    import importlib
+    import io
+    import sys as _sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = io.StringIO('rank noise\n{"metric": "m", "value": 1.5, "n_gpus": 4, "rccl_ranks": 4}\ntrailing\n')
+
+        def wait(self):
+            return 0
+    import subprocess
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--workload", "nsvae_train"])
+    had_torch = "torch" in _sys.modules
+    rc = bench.self_launch(4)
+    out = capsys.readouterr()
+    assert rc == 0
+    assert out.out.strip() == '{"metric": "m", "value": 1.5, "n_gpus": 4, "rccl_ranks": 4}'          # ONE line on stdout
+    assert "rank noise" in out.err and "trailing" in out.err
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--workload", "nsvae_train"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert ("torch" in _sys.modules) == had_torch                       # the launcher itself imports no torch
