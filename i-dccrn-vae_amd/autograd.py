@@ -51,8 +51,7 @@ class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, xbuf, skipbuf, w_re, w_im, b_re, b_im, g_rr, g_ri, g_ii, beta_r, beta_i, slope):
         conv, bn, xg, sg, zero_skip = meta["conv"], meta["bn"], meta["x"], meta["skip"], meta["zero_skip"]
-        if not conv._causal:
-            raise NotImplementedError("training (autograd) is implemented for the causal blocks every shipped recipe uses")
+        causal = conv._causal        # non-causal blocks (model/net_config.py: padding (2, 0), T - 1 / T + 1 frames) train as well
         x = _mk(xbuf, xg)
         skip = _mk(skipbuf, sg) if skipbuf is not None else None
         cin_used = x.C if zero_skip else None
@@ -88,7 +87,7 @@ class ConvBlockFn(torch.autograd.Function):
         # bf16x3 training mode: forward and data gradient on the split-bf16 MFMA kernels where the shape allows
         # (every block but the one-channel ends); weight gradients stay on the fp32 MFMA
         wbf = None
-        if ops.PRECISION == "bf16x3" and ops.bf16_supported(conv._transposed, x.C, skip.C if skip is not None else 0, 1, cout):
+        if causal and ops.PRECISION == "bf16x3" and ops.bf16_supported(conv._transposed, x.C, skip.C if skip is not None else 0, 1, cout):
             wbf = conv.packed_bf16(None, cin_used)
         gauss = conv.gauss_for(x.C, skip.C if skip is not None else 0, None, cin_used) if wbf is None else None
         wfrag, bias = conv.packed(None, cin_used) if gauss is None else (None, None)
@@ -100,7 +99,7 @@ class ConvBlockFn(torch.autograd.Function):
                 y = ops.cconv2d_img_train(_image_of(xbuf, x), wbf, bias, cout, stats, transposed=conv._transposed,
                                           skip=_image_of(skipbuf, skip) if skip is not None else None)
             else:
-                y = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, stats=stats,
+                y = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=causal, skip=skip, stats=stats,
                                 wfrag_bf16=wbf, gauss=gauss)
             first = bool(bn.init_flag)
             moments, fold = ops.cbn_finalize(stats, float(y.B) * y.F * y.T, bn, first, bn.momentum)
@@ -114,7 +113,7 @@ class ConvBlockFn(torch.autograd.Function):
                 z = ops.cbn_apply_to(y, fold, slope)
             ctx.save_for_backward(xbuf, skipbuf, w_re, w_im, y.buf, fold, moments, g_rr, g_ri, g_ii, slope)
         else:
-            z = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=True, skip=skip, wfrag_bf16=wbf, gauss=gauss)
+            z = ops.cconv2d(x, wfrag, bias, cout, transposed=conv._transposed, causal=causal, skip=skip, wfrag_bf16=wbf, gauss=gauss)
             ctx.save_for_backward(xbuf, skipbuf, w_re, w_im, None, None, None, None, None, None, None)
         ctx.meta = meta
         ctx.zgeom = _geom(z)
@@ -170,9 +169,9 @@ class ConvBlockFn(torch.autograd.Function):
             used = x.C + (skip.C if skip is not None else 0)
             mk = torch.zeros_like if used < cin_total else torch.empty_like
             dw_re, dw_im = mk(w_re), mk(w_im)
-            ops.cconv_wgrad(x, 0, dy, cout, cin_total, tr, True, dw_re, dw_im)
+            ops.cconv_wgrad(x, 0, dy, cout, cin_total, tr, conv._causal, dw_re, dw_im)
             if skip is not None:
-                ops.cconv_wgrad(skip, x.C, dy_sum if div > 1 else dy, cout, cin_total, tr, True, dw_re, dw_im)
+                ops.cconv_wgrad(skip, x.C, dy_sum if div > 1 else dy, cout, cin_total, tr, conv._causal, dw_re, dw_im)
         # data gradients: the adjoint operator with conjugate-transposed weights
         dx = dskip = None
         need_x, need_s = ctx.needs_input_grad[1], ctx.needs_input_grad[2] and skip is not None
@@ -180,28 +179,29 @@ class ConvBlockFn(torch.autograd.Function):
             if not tr:      # conv [Cout][Cin]: adjoint = transposed conv, Cin' = Cout, Cout' = Cin (single source)
                 if skip is not None:
                     raise NotImplementedError("conv blocks take one source")
-                dx = _dgrad(dy, w_re, w_im, cin_total, cout, False, dy_img_bn if dy_img_bn is not None else _dy_image(dy, cout))
+                dx = _dgrad(dy, w_re, w_im, cin_total, cout, False, dy_img_bn if dy_img_bn is not None else _dy_image(dy, cout),
+                            causal=conv._causal)
             else:           # transposed conv [Cin][Cout]: adjoint = conv, Cout' = a slice of Cin, Cin' = Cout
                 per = cout * 10
                 dy_img = dy_img_bn if dy_img_bn is not None else _dy_image(dy, cout)
                 if need_x:
-                    dx = _dgrad(dy, w_re, w_im, x.C, cout, True, dy_img)
+                    dx = _dgrad(dy, w_re, w_im, x.C, cout, True, dy_img, causal=conv._causal)
                 if need_s:
                     wr, wi = w_re.reshape(-1)[x.C * per:], w_im.reshape(-1)[x.C * per:]
                     if div > 1:
                         dskip = _dgrad(dy_sum, wr, wi, skip.C, cout, True, None)
                     else:
-                        dskip = _dgrad(dy, wr, wi, skip.C, cout, True, dy_img)
+                        dskip = _dgrad(dy, wr, wi, skip.C, cout, True, dy_img, causal=conv._causal)
         return (None, _fit(dx, xbuf) if dx is not None else None, _fit(dskip, skipbuf) if dskip is not None else None,
                 dw_re, dw_im, db_re, db_im) + grads_bn
 
 
-def _dgrad(dy: Planar, w_re, w_im, cout_adj: int, cin_adj: int, fwd_transposed: bool, dy_img=None) -> Planar:
+def _dgrad(dy: Planar, w_re, w_im, cout_adj: int, cin_adj: int, fwd_transposed: bool, dy_img=None, causal: bool = True) -> Planar:
     """Adjoint operator with conjugate-transposed weights.  bf16x3 mode, where the shape allows: the split-bf16 kernel, fed
     with the split IMAGE of dy (dy_img, made once per block by the caller) when the image kernels take the shape -- they
     stage by LDS-DMA instead of splitting the fp32 patch in registers, 1.5x faster than the planar-source form."""
     adj_tr = not fwd_transposed
-    if ops.PRECISION == "bf16x3" and ops.bf16_supported(adj_tr, cin_adj, 0, 1, cout_adj):
+    if causal and ops.PRECISION == "bf16x3" and ops.bf16_supported(adj_tr, cin_adj, 0, 1, cout_adj):
         w16 = ops.pack_cconv_bf16_adjoint(w_re, w_im, cout_adj, cin_adj, cin_adj, adj_tr)
         zb = ops.zero_bias(cout_adj, w_re.device)
         if dy_img is not None and cout_adj % 4 == 0:
@@ -211,9 +211,9 @@ def _dgrad(dy: Planar, w_re, w_im, cout_adj: int, cin_adj: int, fwd_transposed: 
     if ops.PRECISION == "fp32" and ops.gauss_supported(cin_adj, 0, cout_adj, bwd=True):
         # exact fp32 with three real products per complex product (csrc/cgemm_gauss.hip)
         g3 = ops.pack_cconv_gauss(w_re, w_im, None, None, None, adjoint_of=(cout_adj, cin_adj, cin_adj, adj_tr))
-        return ops.cconv_dgrad(dy, None, None, cout_adj, fwd_transposed, True, gauss=g3)
+        return ops.cconv_dgrad(dy, None, None, cout_adj, fwd_transposed, causal, gauss=g3)
     wf, bz = ops.pack_cconv_adjoint(w_re, w_im, cout_adj, cin_adj, cin_adj, adj_tr)
-    return ops.cconv_dgrad(dy, wf, bz, cout_adj, fwd_transposed, True)
+    return ops.cconv_dgrad(dy, wf, bz, cout_adj, fwd_transposed, causal)
 
 
 def _image_of(buf: torch.Tensor, pl: Planar):
@@ -255,7 +255,8 @@ def conv_block(conv, bn, prelu_weight, x: Planar, skip: Optional[Planar], zero_s
     Fout = 2 * x.F - 1 if conv._transposed else (x.F - 1) // 2 + 1
     zbuf = ConvBlockFn.apply(meta, x.buf, skip.buf if skip is not None else None, re.weight, im.weight, re.bias, im.bias, *bnp,
                              prelu_weight if bn is not None else None)
-    return Planar(zbuf, cout, Fout, x.B, x.T, x.Tp, x.Jp)
+    t_out = x.T if conv._causal else (x.T + 1 if conv._transposed else x.T - 1)
+    return Planar(zbuf, cout, Fout, x.B, t_out, x.Tp, x.Jp)
 
 
 # ----------------------------------------------------------------------------- stand-alone ComplexBatchNormal

@@ -834,11 +834,20 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
     """Data gradient of a causal_complex_conv2d / causal_ComplexConvTranspose2d: the adjoint operator on idv_cconv2d_fwd
     (transposed conv reading (dy[t+1], dy[t]) / conv reading (dy[t], dy[t+1]); all T frames kept: column T+1 is the next
     utterance's zero guard column).  wfrag_bf16: run it on the split-bf16 kernel instead (bf16x3 training mode)."""
-    if not causal:
-        raise NotImplementedError("data gradients are implemented for the causal blocks")
     adj_transposed = not fwd_transposed
     Fout = 2 * dy.F - 1 if adj_transposed else (dy.F - 1) // 2 + 1
-    out = Planar.empty(cout_adj, Fout, dy.B, dy.T, dy.Tp, dy.buf.device)
+    # causal blocks: time taps reversed (tshift 0), T frames in, T frames out.  Non-causal blocks (padding (2, 0)): the adjoint of
+    # the conv (T -> T - 1 frames) is the transposed conv's own tap order (dx[t] = W0' dy[t] + W1' dy[t-1], tshift -1) on T frames;
+    # the adjoint of the transposed conv (T -> T + 1) is the non-causal conv's (dx[t] = W0' dy[t] + W1' dy[t+1], tshift 0) on T frames
+    if causal:
+        tshift_adj, t_out = 0, dy.T
+    elif adj_transposed:
+        tshift_adj, t_out = -1, dy.T + 1
+    else:
+        tshift_adj, t_out = 0, dy.T - 1
+    if t_out + 1 > dy.Tp:
+        raise RuntimeError("cconv_dgrad: the input of the block had more frames than the buffer's columns per utterance")
+    out = Planar.empty(cout_adj, Fout, dy.B, t_out, dy.Tp, dy.buf.device)
     if LAUNCH_LOG is not None:
         cfg = L.lib().idv_cconv_config(i(1 if adj_transposed else 0), i(dy.C), i(cout_adj), i(dy.F))
         macs = 4 * dy.C * cout_adj * 10 * dy.B * dy.T * (dy.F if adj_transposed else Fout)
@@ -850,12 +859,12 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
         if LAUNCH_LOG is not None:
             cfg = L.lib().idv_cconv_gauss_config(i(1 if adj_transposed else 0), i(cout_adj), i(dy.F))
         call("idv_cconv2d_gauss_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(gauss[0]), p(gauss[1]), i(0), p(None),
-             out.ptr(), p(None), i(1 if adj_transposed else 0), i(0), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(dy.T),
-             p(None), i(1), i(0), stream_ptr())
+             out.ptr(), p(None), i(1 if adj_transposed else 0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp),
+             i(t_out), p(None), i(1), i(0), stream_ptr())
     else:
         call("idv_cconv2d_bf16x3_fwd" if wfrag_bf16 is not None else "idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1),
              p(wfrag_bf16 if wfrag_bf16 is not None else wfrag), p(bias), p(None), out.ptr(), p(None),
-             i(1 if adj_transposed else 0), i(0), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(dy.T), stream_ptr())
+             i(1 if adj_transposed else 0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), stream_ptr())
     if LAUNCH_LOG is not None:
         ev1.record()
         LAUNCH_LOG.append((cfg, macs, ev0, ev1))

@@ -120,6 +120,17 @@ def test_wgrad_bf16_offsets_beyond_2_gib(ops):
         assert float((a - b).norm() / a.norm()) < 1e-4
 
 
+@pytest.mark.parametrize("transposed,cin,cout,F,T,B,skip_c,bn", [
+    (False, 4, 8, 17, 9, 2, 0, True), (False, 32, 64, 17, 40, 2, 0, True), (True, 8, 4, 9, 12, 2, 4, True),
+    (True, 64, 32, 5, 33, 2, 64, True), (False, 8, 16, 9, 21, 3, 0, False), (True, 16, 8, 5, 19, 2, 0, False),
+])
+def test_conv_block_grads_noncausal(ops, pm, cp, transposed, cin, cout, F, T, B, skip_c, bn):
+    """The NON-causal blocks of model/net_config.py (padding (2, 0): the conv drops a frame, the transposed conv adds one;
+    reference model/complex_progress.py:24-36, :253-279) through the same autograd.Function: forward, data gradient (the adjoint
+    with the other tap alignment), skip gradient, weight / bias / batch-norm / PReLU gradients against float64 autograd."""
+    _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, 2e-5, GTOL, causal=False)
+
+
 @pytest.mark.parametrize("transposed,cx,cout,cin_total,ci_off,F,T,B", [
     (False, 32, 128, 32, 0, 33, 40, 3),       # conv, one S tile
     (False, 96, 160, 96, 0, 17, 29, 2),       # conv, ragged S and L tiles
@@ -159,16 +170,17 @@ def test_wgrad_gauss_matches_four_product_kernel(ops, transposed, cx, cout, cin_
     assert float((sl - 7.0).abs().min()) > 0 and float((outs[1][0] == 7.0).sum()) == outs[1][0].numel() - sl.numel()
 
 
-def _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, ftol, gtol):
+def _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, ftol, gtol, causal=True):
     g = torch.Generator().manual_seed(3)
     dev = "cuda"
     cin_tot = cin + skip_c
     Fout = 2 * F - 1 if transposed else (F - 1) // 2 + 1
+    Tout = T if causal else (T + 1 if transposed else T - 1)
     if transposed:
-        blk = pm.Decoder(cin_tot, cout, (5, 2), (2, 1), (cout, Fout, T), (2, 0), causal=True, if_bn=bn)
+        blk = pm.Decoder(cin_tot, cout, (5, 2), (2, 1), (cout, Fout, T), (2, 0), causal=causal, if_bn=bn)
         conv = blk.transconv
     else:
-        blk = pm.Encoder(cin_tot, cout, (5, 2), (2, 1), (cout, Fout, T), (2, 1), causal=True)
+        blk = pm.Encoder(cin_tot, cout, (5, 2), (2, 1), (cout, Fout, T), (2, 1) if causal else (2, 0), causal=causal)
         conv = blk.conv
     with torch.no_grad():
         for p_ in blk.parameters():
@@ -177,12 +189,12 @@ def _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, ftol,
     blk = blk.to(dev)
     x = rnd(g, B, cin, F, T, 2)
     sk = rnd(g, B, skip_c, F, T, 2) if skip_c else None
-    R = rnd(g, B, cout, Fout, T, 2)
-    xp = ops.Planar.from_tensor5(x.to(dev))
+    R = rnd(g, B, cout, Fout, Tout, 2)
+    xp = ops.Planar.from_tensor5(x.to(dev), T + 2)
     xp.buf.requires_grad_(True)
     skp = None
     if sk is not None:
-        skp = ops.Planar.from_tensor5(sk.to(dev))
+        skp = ops.Planar.from_tensor5(sk.to(dev), T + 2)
         skp.buf.requires_grad_(True)
     with torch.enable_grad():
         if transposed:
@@ -202,9 +214,9 @@ def _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, ftol,
     n = "transconv.tconv" if transposed else "conv.conv"
     args = (sd[f"{n}_re.weight"], sd[f"{n}_re.bias"], sd[f"{n}_im.weight"], sd[f"{n}_im.bias"])
     if transposed:
-        y = O.complex_conv_transpose2d(xin, *args, (2, 1), (2, 0), True)
+        y = O.complex_conv_transpose2d(xin, *args, (2, 1), (2, 0), causal)
     else:
-        y = O.complex_conv2d(xin, *args, (2, 1), (2, 1), True)
+        y = O.complex_conv2d(xin, *args, (2, 1), (2, 1) if causal else (2, 0), causal)
     if bn:
         st = O.cbn_batch_stats(y)
         y = O.cbn_whiten_affine(y, *st, sd["bn.gamma_rr"], sd["bn.gamma_ri"], sd["bn.gamma_ii"], sd["bn.beta_r"], sd["bn.beta_i"])
@@ -699,6 +711,48 @@ def test_end_to_end_encoder_decoder_grads_with_repeated_skips(pm, losses):
             check(k, p_.grad, want, 1e-3)
             n += 1
     assert n > 60
+
+
+def test_noncausal_dccrn_train_step_grads(pm, losses):
+    """The non-causal DCCRN (model/net_config.py; VERDICT r2 'missing' 5a) as a TRAIN step: forward(train=True) + final_ete_loss +
+    backward through the HIP autograd path against torch.autograd through the oracle in float64 -- loss, input gradient and every
+    parameter gradient (mini width: no PReLU pre-activation sits within rounding of zero here, so 1e-3 holds)."""
+    nl, _, _ = losses
+    np_ = O.net_params(False, 4)
+    m = load_synth(pm.DCCRN_(NFFT, HOP, np_, False, "cuda", WIN, SKIP, "mask", False, None, None), 31)
+    m.train()
+    g = torch.Generator().manual_seed(5)
+    x = rnd(g, 2, 2400, scale=0.1)
+    c = x + rnd(g, 2, 2400, scale=0.05)
+    xg = x.cuda().requires_grad_(True)
+    w = [0.3, 0.2, 1.0]
+    with torch.enable_grad():
+        est, pred = m(xg, train=True)
+        loss = nl.ete_train_se_loss(w).final_ete_loss(pred, m.stft(c.cuda()), c.cuda(), est)[0]
+        loss.backward()
+    sd = {k: v.detach().cpu().double().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    for k in list(sd):
+        if ".bn.running" in k or k.endswith((".Vrr", ".Vri", ".Vii")):
+            sd[k] = sd[k].detach()
+    x64 = x.double().clone().requires_grad_(True)
+    o_est, o_pred, _ = O.dccrn_forward(x64, sd, np_, False, NFFT, HOP, WIN, SKIP, "mask", True, O.BNState())
+    o_loss = O.multiple_recon_loss(o_pred, O.stft(c.double(), NFFT, HOP, WIN), c.double(), o_est, w)[0]
+    o_loss.backward()
+    assert tuple(est.shape) == tuple(o_est.shape)
+    assert abs(float(loss.detach()) - float(o_loss)) < 2e-4 * abs(float(o_loss))
+    check("waveform", est, o_est.detach(), 1e-4)
+    check("input gradient", xg.grad, x64.grad, 1e-3)
+    n = 0
+    for k, p_ in m.named_parameters():
+        want = sd[k].grad
+        if want is None:
+            assert p_.grad is None or float(p_.grad.abs().max()) == 0.0, k
+            continue
+        if k.endswith("conv_re.bias") or k.endswith("conv_im.bias"):
+            continue                                    # true-zero gradients in front of a batch norm
+        check(k, p_.grad, want, 1e-3 if p_.numel() > 1 else 3e-3)
+        n += 1
+    assert n > 100
 
 
 _FULL_WIDTH_ORACLE = {}
