@@ -536,6 +536,55 @@ class MaskFn(torch.autograd.Function):
         return None, None, None, _fit(dm, maskbuf), _fit(dX, Xbuf) if dX is not None else None
 
 
+class DatanormFn(torch.autograd.Function):
+    """Input normalisation of DCCRN_.forward (pvae_module.py:217-221)."""
+
+    @staticmethod
+    def forward(ctx, geom, mean, std, Xbuf):
+        X = _mk(Xbuf, geom)
+        out = Planar.empty(1, X.F, X.B, X.T, X.Tp, Xbuf.device)
+        call("idv_datanorm", X.ptr(), p(mean), p(std), i(X.F), i(X.B), i(X.T), i(X.Tp), i(X.Jp), out.ptr(), stream_ptr())
+        ctx.geom = geom
+        ctx.save_for_backward(std, Xbuf)
+        return out.buf
+
+    @staticmethod
+    def backward(ctx, dobuf):
+        std, Xbuf = ctx.saved_tensors
+        X = _mk(Xbuf, ctx.geom)
+        do = _mk(dobuf.contiguous(), ctx.geom)
+        dX = ops.like(X)
+        call("idv_datanorm_bwd", do.ptr(), p(std), i(X.F), i(X.B), i(X.T), i(X.Tp), i(X.Jp), dX.ptr(), stream_ptr())
+        return None, None, None, _fit(dX, Xbuf)
+
+
+class DatadenormFn(torch.autograd.Function):
+    """predict = data_std * predict + data_mean (pvae_module.py:235-238, :246-247) -> (planar, interleaved complex)."""
+
+    @staticmethod
+    def forward(ctx, geom, mean, std, Pbuf):
+        P_ = _mk(Pbuf, geom)
+        out = Planar.empty(1, P_.F, P_.B, P_.T, P_.Tp, Pbuf.device)
+        pc = torch.empty(P_.B, P_.F, P_.T, 2, dtype=torch.float32, device=Pbuf.device)
+        call("idv_datadenorm", P_.ptr(), p(mean), p(std), i(P_.F), i(P_.B), i(P_.T), i(P_.Tp), i(P_.Jp), out.ptr(), p(pc), stream_ptr())
+        ctx.geom = geom
+        ctx.save_for_backward(std, Pbuf)
+        ctx.set_materialize_grads(False)
+        return out.buf, pc
+
+    @staticmethod
+    def backward(ctx, dobuf, dpc):
+        std, Pbuf = ctx.saved_tensors
+        if dobuf is None and dpc is None:
+            return None, None, None, None
+        P_ = _mk(Pbuf, ctx.geom)
+        do = _mk(dobuf.contiguous(), ctx.geom) if dobuf is not None else None
+        dP = ops.like(P_)
+        call("idv_datadenorm_bwd", do.ptr() if do is not None else p(None), p(dpc.contiguous().float()) if dpc is not None else p(None),
+             p(std), i(P_.F), i(P_.B), i(P_.T), i(P_.Tp), i(P_.Jp), dP.ptr(), stream_ptr())
+        return None, None, None, _fit(dP, Pbuf)
+
+
 class PlanarToComplexFn(torch.autograd.Function):
     """recon_type 'real_imag' (pvae_module.py:245-253): planar [2][1][F][Jp] -> interleaved [B, F, T, 2]."""
 

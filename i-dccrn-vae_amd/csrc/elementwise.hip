@@ -323,6 +323,37 @@ __global__ void datadenorm_kernel(const float* __restrict__ P, const float* __re
     }
 }
 
+// backward of datanorm_kernel: dX = dout / (std + 1e-6), the imaginary parts of the first and last bin carry no gradient
+__global__ void datanorm_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ stdv, int F, int B, int T, int Tp,
+                                    int Jp, float* __restrict__ dX) {
+    const long long n = (long long)B * F * T;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % T);
+        const int f = (int)((idx / T) % F);
+        const int b = (int)(idx / ((long long)T * F));
+        const size_t j = (size_t)f * Jp + (size_t)b * Tp + t + 1;
+        dX[j] = dout[j] / (stdv[2 * f] + 1e-6f);
+        dX[(size_t)F * Jp + j] = (f == 0 || f == F - 1) ? 0.f : dout[(size_t)F * Jp + j] / (stdv[2 * f + 1] + 1e-6f);
+    }
+}
+
+// backward of datadenorm_kernel: dP = std * (gradient of the planar output + gradient of the interleaved complex output)
+__global__ void datadenorm_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ dout_c, const float* __restrict__ stdv,
+                                      int F, int B, int T, int Tp, int Jp, float* __restrict__ dP) {
+    const long long n = (long long)B * F * T;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % T);
+        const int f = (int)((idx / T) % F);
+        const int b = (int)(idx / ((long long)T * F));
+        const size_t j = (size_t)f * Jp + (size_t)b * Tp + t + 1;
+        float gr = 0.f, gi = 0.f;
+        if (dout) { gr += dout[j]; gi += dout[(size_t)F * Jp + j]; }
+        if (dout_c) { gr += dout_c[idx * 2]; gi += dout_c[idx * 2 + 1]; }
+        dP[j] = stdv[2 * f] * gr;
+        dP[(size_t)F * Jp + j] = stdv[2 * f + 1] * gi;
+    }
+}
+
 __global__ void zero_guard_kernel(float* __restrict__ act, int planes, int B, int Tp, int Jp) {
     const long long n = (long long)planes * B;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x)
@@ -378,6 +409,25 @@ extern "C" int idv_datadenorm(const float* P, const float* mean, const float* st
     if (hipMemsetAsync(out, 0, sizeof(float) * 2 * (size_t)F * Jp, st) != hipSuccess) return IDV_ELAUNCH;
     hipLaunchKernelGGL(datadenorm_kernel, dim3(grid_for((long long)B * F * T)), dim3(256), 0, st, P, mean, stdv, F, B, T, Tp, Jp,
                        out, out_c);
+    return idv_launch_status();
+}
+
+// gradients of idv_datanorm / idv_datadenorm (training with the reference's --data_norm; model/pvae_module.py:217-221, :235-238)
+extern "C" int idv_datanorm_bwd(const float* dout, const float* stdv, int F, int B, int T, int Tp, int Jp, float* dX, void* stream) {
+    if (!dout || !stdv || !dX || F <= 0 || B <= 0 || T <= 0 || Tp < T + 1) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dX, 0, sizeof(float) * 2 * (size_t)F * Jp, st) != hipSuccess) return IDV_ELAUNCH;
+    hipLaunchKernelGGL(datanorm_bwd_kernel, dim3(grid_for((long long)B * F * T)), dim3(256), 0, st, dout, stdv, F, B, T, Tp, Jp, dX);
+    return idv_launch_status();
+}
+
+extern "C" int idv_datadenorm_bwd(const float* dout, const float* dout_c, const float* stdv, int F, int B, int T, int Tp, int Jp,
+                                  float* dP, void* stream) {
+    if ((!dout && !dout_c) || !stdv || !dP || F <= 0 || B <= 0 || T <= 0 || Tp < T + 1) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dP, 0, sizeof(float) * 2 * (size_t)F * Jp, st) != hipSuccess) return IDV_ELAUNCH;
+    hipLaunchKernelGGL(datadenorm_bwd_kernel, dim3(grid_for((long long)B * F * T)), dim3(256), 0, st, dout, dout_c, stdv, F, B, T, Tp,
+                       Jp, dP);
     return idv_launch_status();
 }
 

@@ -35,6 +35,30 @@ __global__ __launch_bounds__(256) void sisnr_partial_kernel(const float* __restr
     block_add3(E, D, Q, work + (size_t)b * 3);
 }
 
+// sum over (part, c < C, f, b, t <= t_valid) of (a[ca0 + c] - b[cb0 + c])^2 between two planar activations: the skip-matching
+// ("residual") term of model/nsvae_loss.py:363-446, torch.mean((connct - connct2).pow(2)) per skip connection
+__global__ __launch_bounds__(256) void msd_partial_kernel(const float* __restrict__ a, int Ca, int ca0, int JpA,
+                                                          const float* __restrict__ b, int Cb, int cb0, int JpB, int C, int F,
+                                                          int B, int Tp, int t_valid, double* __restrict__ work) {
+    const int row = blockIdx.y;                       // (part, c, f)
+    const int f = row % F, c = (row / F) % C, part = row / (F * C);
+    const float* pa = a + ((size_t)(part * Ca + ca0 + c) * F + f) * JpA;
+    const float* pb = b + ((size_t)(part * Cb + cb0 + c) * F + f) * JpB;
+    const int J = B * Tp;
+    double acc = 0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < J; j += gridDim.x * blockDim.x) {
+        const int tp = j % Tp;
+        if (tp < 1 || tp > t_valid) continue;
+        const float d = pa[j] - pb[j];
+        acc += (double)d * d;
+    }
+    block_add3(acc, 0.0, 0.0, work);
+}
+
+__global__ void msd_final_kernel(const double* __restrict__ work, double count, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(work[0] / count);
+}
+
 // s_target = (D/(E+eps)) s ; |s_t|^2 = a^2 E ; |e - s_t|^2 = Q - 2aD + a^2 E   (sisnr_loss.py:10-18)
 __global__ void sisnr_final_kernel(const double* __restrict__ work, int B, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -202,6 +226,23 @@ extern "C" int idv_sisdr(const float* ref, int ref_ld, const float* est, int est
     if (hipMemsetAsync(work, 0, sizeof(double) * 3 * B, st) != hipSuccess) return IDV_ELAUNCH;
     hipLaunchKernelGGL(sisnr_partial_kernel, dim3(grid_for(L, 64), B), dim3(256), 0, st, ref, ref_ld, 1, est, est_ld, L, work);
     hipLaunchKernelGGL(sisdr_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, work, B, out);
+    return idv_launch_status();
+}
+
+// mean squared difference between C channels of two planar activations (both parts): out[0] = mean over [B, C, F, T, 2] of
+// (a[:, ca0:ca0+C] - b[:, cb0:cb0+C])^2 -- one term of residual_loss (model/nsvae_loss.py:363-446).  work: 3 doubles.
+extern "C" int idv_msd(const float* a, int Ca, int ca0, int JpA, const float* b, int Cb, int cb0, int JpB, int C, int F, int B,
+                       int Tp, int t_valid, double* work, float* out, void* stream) {
+    if (!a || !b || !work || !out || C <= 0 || F <= 0 || B <= 0 || Tp <= 1 || t_valid < 1 || t_valid >= Tp || ca0 < 0 || cb0 < 0 ||
+        ca0 + C > Ca || cb0 + C > Cb || JpA < B * Tp || JpB < B * Tp)
+        return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(work, 0, sizeof(double) * 3, st) != hipSuccess) return IDV_ELAUNCH;
+    int gx = (B * Tp + 255) / 256;
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(msd_partial_kernel, dim3(gx, 2 * C * F), dim3(256), 0, st, a, Ca, ca0, JpA, b, Cb, cb0, JpB, C, F, B, Tp,
+                       t_valid, work);
+    hipLaunchKernelGGL(msd_final_kernel, dim3(1), dim3(64), 0, st, work, 2.0 * C * F * (double)B * t_valid, out);
     return idv_launch_status();
 }
 

@@ -5,6 +5,7 @@ import torch
 from .. import autograd as AG
 from .. import ops
 from ._loss_common import kl_mean, latent_ref, recon_terms
+from .complex_progress import planar_of
 from .sisnr_loss import si_snr as _si_snr
 
 
@@ -14,6 +15,13 @@ def _miu_dist(miu_a, miu_b):
     if AG.grad_mode(pa.buf, pb.buf):
         return AG.MiuDistFn.apply(AG._geom(pa), oa[0], AG._geom(pb), ob[0], miu_a.shape[2], pa.buf, pb.buf)
     return ops.miu_dist(pa, oa[0], pb, ob[0], miu_a.shape[2])
+
+
+def _msd(a, ca0, b, cb0, C):
+    """mean over [B, C, F, T, 2] of (a[:, ca0:ca0+C] - b[:, cb0:cb0+C])^2 for two planar activations (idv_msd)."""
+    if (a.F, a.B, a.T, a.Tp) != (b.F, b.B, b.T, b.Tp):
+        raise RuntimeError(f"residual loss: skip connections of different shape ({(a.B, a.F, a.T)} vs {(b.B, b.F, b.T)})")
+    return ops.msd(a, ca0, b, cb0, C)
 
 
 class _KLMixin:
@@ -60,15 +68,42 @@ class standard_nsvae_loss_true_kl(_KLMixin):
                          log_sigma_noisy_speech, log_sigma_noisy_noise, delta_clean, delta_noise, delta_noisy_speech,
                          delta_noisy_noise, z_noisy_speech, z_noisy_noise, skiper_clean, skiper_noise, skiper_noisy):
         """reference :448-473 -> (final, kl, kl_clean, kl_noise, dismiu_speech, dismiu_noise, resi, resi_speech, resi_noise)"""
-        if self.skipc == 'True' and self.w_resi != 0:
-            raise NotImplementedError("residual (skip-matching) loss: w_resi is 0 in the shipped recipe")
         kl_loss, kl_clean, kl_noise = self.kl_loss(miu_clean, miu_noise, miu_noisy_speech, miu_noisy_noise,
                                                    log_sigma_clean, log_sigma_noise, log_sigma_noisy_speech,
                                                    log_sigma_noisy_noise, delta_clean, delta_noise, delta_noisy_speech,
                                                    delta_noisy_noise, z_noisy_speech, z_noisy_noise)
         dismiu_loss, dismiu_speech, dismiu_noise = self.miu_dis_loss(miu_clean, miu_noise, miu_noisy_speech, miu_noisy_noise)
         final_loss = self.w_kl * kl_loss + self.w_dismiu * dismiu_loss
-        return final_loss, kl_loss, kl_clean, kl_noise, dismiu_speech, dismiu_noise, 0, 0, 0
+        resi = (0, 0, 0)
+        if self.skipc == 'True' and self.w_resi != 0:
+            # computed and returned, NOT added to the loss that is back-propagated: exactly the reference (:460-466)
+            resi = self.residual_loss(skiper_clean, skiper_noise, skiper_noisy)
+        return (final_loss, kl_loss, kl_clean, kl_noise, dismiu_speech, dismiu_noise) + tuple(resi)
+
+    def residual_loss(self, skiper_clean, skiper_noise, skiper_noisy):
+        """Skip-matching term, reference :363-446: per used skip connection the mean squared difference between the clean (and
+        noise) encoder's skip and the noisy encoder's -- its first / second half of the channels where the model carries both
+        (`skiper_split`, matching 'both') -> (total, speech, noise).  A value for the log, no gradient (see final_nsvae_loss)."""
+        n = len(skiper_clean)
+        used = [idx for idx in range(n) if (n - 1 - idx) in self.skip_to_use]
+        split = self.skiper_split if (self.latent_num == 1 or self.matching == 'speech') else True
+        both = self.latent_num == 2 and self.matching == 'both'
+        if self.latent_num == 2 and self.matching not in ('both', 'speech'):
+            raise ValueError(f"matching {self.matching!r}")
+        speech = noise = 0
+        for idx in used:
+            c = planar_of(skiper_clean[idx])
+            y = planar_of(skiper_noisy[idx], c.Tp)
+            half = y.C // 2 if split else y.C
+            if c.C != half:              # torch's own shape error for (connct - connct2) in the reference
+                raise RuntimeError(f"residual loss: clean skip has {c.C} channels, the noisy encoder's {'half' if split else 'skip'} {half}")
+            speech = speech + _msd(c, 0, y, 0, half)
+            if both:
+                nz = planar_of(skiper_noise[idx], c.Tp)
+                if nz.C != y.C - half:
+                    raise RuntimeError(f"residual loss: noise skip has {nz.C} channels, the noisy encoder's second half {y.C - half}")
+                noise = noise + _msd(nz, 0, y, half, y.C - half)
+        return speech + noise, speech, noise
 
 
 class ete_train_se_loss():

@@ -281,8 +281,11 @@ class standard_DCCRN(nn.Module):
         return tag5(self.forward_planar(planar_of(x), train))
 
 
-def _apply_datanorm(stft: Planar, mean, std) -> Planar:
+def _apply_datanorm(stft: Planar, mean, std, train: bool = False) -> Planar:
     """Optional input normalisation of DCCRN_.forward (pvae_module.py:217-221); off in the shipped recipes."""
+    if train and torch.is_grad_enabled():
+        buf = AG.DatanormFn.apply(AG._geom(stft), mean.reshape(-1).float().contiguous(), std.reshape(-1).float().contiguous(), stft.buf)
+        return ops.rewrap(buf, stft)
     out = Planar.empty(1, stft.F, stft.B, stft.T, stft.Tp, stft.buf.device)
     ops.call("idv_datanorm", stft.ptr(), ops.p(mean.reshape(-1).float().contiguous()), ops.p(std.reshape(-1).float().contiguous()),
              ops.i(stft.F), ops.i(stft.B), ops.i(stft.T), ops.i(stft.Tp), ops.i(stft.Jp), out.ptr(), ops.stream_ptr())
@@ -291,6 +294,10 @@ def _apply_datanorm(stft: Planar, mean, std) -> Planar:
 
 def _invert_datanorm(pred: Planar, mean, std):
     """predict = data_std * predict + data_mean (pvae_module.py:235-238) -> (planar, complex [B, F, T])."""
+    if AG.grad_mode(pred.buf):
+        obuf, pc = AG.DatadenormFn.apply(AG._geom(pred), mean.reshape(-1).float().contiguous(), std.reshape(-1).float().contiguous(),
+                                         pred.buf)
+        return ops.rewrap(obuf, pred), torch.view_as_complex(pc)
     out = Planar.empty(1, pred.F, pred.B, pred.T, pred.Tp, pred.buf.device)
     pc = torch.empty(pred.B, pred.F, pred.T, 2, dtype=torch.float32, device=pred.buf.device)
     ops.call("idv_datadenorm", pred.ptr(), ops.p(mean.reshape(-1).float().contiguous()), ops.p(std.reshape(-1).float().contiguous()),
@@ -380,9 +387,7 @@ class DCCRN_(nn.Module):
 
     def _forward_one(self, signal, train, on_encoded=None):
         X = self.stft.planar(signal)
-        if self.datanorm and train and torch.is_grad_enabled():
-            raise NotImplementedError("training with data normalisation (--data_norm is off in the shipped recipe)")
-        net_in = _apply_datanorm(X, self.data_mean, self.data_std) if self.datanorm else X
+        net_in = _apply_datanorm(X, self.data_mean, self.data_std, train) if self.datanorm else X
         out = self.std_DCCRN.forward_planar(net_in, train=train, on_encoded=on_encoded)
         pred, predict = _predict_outputs(self, out, net_in, self.recon_type)
         if self.datanorm:

@@ -674,6 +674,15 @@ def mask_apply(mask: Planar, X: Planar, x_div: int = 1):
     return pred, torch.view_as_complex(pc)
 
 
+def msd(a: Planar, ca0: int, b: Planar, cb0: int, C: int) -> torch.Tensor:
+    """One term of residual_loss (nsvae_loss.py:363-446): mean over [B, C, F, T, 2] of (a[:, ca0:ca0+C] - b[:, cb0:cb0+C])^2."""
+    work = torch.empty(3, dtype=torch.float64, device=a.buf.device)
+    out = torch.empty(1, dtype=torch.float32, device=a.buf.device)
+    call("idv_msd", a.ptr(), i(a.C), i(ca0), i(a.Jp), b.ptr(), i(b.C), i(cb0), i(b.Jp), i(C), i(a.F), i(a.B), i(a.Tp), i(a.T),
+         p(work), p(out), stream_ptr())
+    return out[0]
+
+
 def planar_to_complex(act: Planar) -> torch.Tensor:
     pc = torch.empty(act.B, act.F, act.T, 2, dtype=torch.float32, device=act.buf.device)
     call("idv_planar_to_complex", act.ptr(), p(pc), i(act.F), i(act.B), i(act.T), i(act.Tp), i(act.Jp), stream_ptr())

@@ -224,6 +224,11 @@ int idv_mask_apply(const float* mask, const float* X, int x_div, int JpX, float*
 int idv_datanorm(const float* X, const float* mean, const float* stdv, int F, int B, int T, int Tp, int Jp, float* out, void* stream);
 int idv_datadenorm(const float* P, const float* mean, const float* stdv, int F, int B, int T, int Tp, int Jp, float* out,
                    float* out_c, void* stream);
+/* gradients of the two (training with the reference's --data_norm): dX = dout / (std + 1e-6) with no gradient for the imaginary
+ * parts of the first and last bin; dP = std * (dout + dout_c), either gradient may be NULL. */
+int idv_datanorm_bwd(const float* dout, const float* stdv, int F, int B, int T, int Tp, int Jp, float* dX, void* stream);
+int idv_datadenorm_bwd(const float* dout, const float* dout_c, const float* stdv, int F, int B, int T, int Tp, int Jp, float* dP,
+                       void* stream);
 /* Two-latent enhancement estimators of the evaluation script (i_dccrn_vae/nsvae_dccrn/test_se_cvaefinetune.py:
  * real_and_imag_mask :85-101, complex_mask :104-116, phase_sensitive_mask :119-135, applied at :283-305): S / N = mean over the
  * ns sampled speech / noise spectra of an utterance, X = its noisy spectrum.  mode 0: per-part Wiener-like masks
@@ -349,6 +354,12 @@ int idv_recon_loss(const float* pred_c, const float* ori, long long sb, long lon
 int idv_ckl(const float* q1, int H1, int Jp1, int o1_miu, int o1_ls, int o1_dl, const float* q2, int H2, int Jp2,
             int o2_miu, int o2_ls, int o2_dl, int zdim, float eps, int B, int T, int Tp, double* work, float* out,
             void* stream);
+/* One term of residual_loss (model/nsvae_loss.py:363-446: torch.mean((connct - connct2).pow(2)) per skip connection): the mean
+ * over [B, C, F, T, 2] of (a[:, ca0:ca0+C] - b[:, cb0:cb0+C])^2 for two planar activations with Ca / Cb channels.  The reference
+ * computes and RETURNS the term but never adds it to the loss it back-propagates (:460-466), so there is no gradient entry.
+ * work: 3 doubles. */
+int idv_msd(const float* a, int Ca, int ca0, int JpA, const float* b, int Cb, int cb0, int JpB, int C, int F, int B, int Tp,
+            int t_valid, double* work, float* out, void* stream);
 /* miu_dis_loss term (model/nsvae_loss.py:349-360): sqrt(sum_{h,ri} mean_{b,t} (miu1 - miu2)^2). */
 int idv_miu_dist(const float* q1, int H1, int Jp1, int off1, const float* q2, int H2, int Jp2, int off2, int zdim,
                  int B, int T, int Tp, double* work, float* out, void* stream);

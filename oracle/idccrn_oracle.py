@@ -436,6 +436,25 @@ def sisdr_np(x_est, x_ref):
     return 10 * np.log10((eps + (e_true ** 2).sum()) / (eps + (e_res ** 2).sum()))
 
 
+def residual_loss(skiper_clean, skiper_noise, skiper_noisy, skip_to_use, latent_num, skiper_split, matching):
+    """standard_nsvae_loss_true_kl.residual_loss, model/nsvae_loss.py:363-446: per used skip connection the mean squared
+    difference between the clean (noise) encoder's skip and the noisy encoder's (its first / second half of the channels when
+    split) -> (total, speech, noise).  Pinned by op_resi.npz (make_golden.py resi: the reference class itself)."""
+    n = len(skiper_clean)
+    split = skiper_split if (latent_num == 1 or matching == "speech") else True
+    speech, noise = 0, 0
+    for idx in range(n):
+        if (n - 1 - idx) not in skip_to_use:
+            continue
+        y = skiper_noisy[idx]
+        half = y.shape[1] // 2
+        ys = y[:, :half] if split else y
+        speech = speech + torch.mean((skiper_clean[idx] - ys).pow(2))
+        if latent_num == 2 and matching == "both":
+            noise = noise + torch.mean((skiper_noise[idx] - y[:, half:]).pow(2))
+    return speech + noise, speech, noise
+
+
 def net_params(causal: bool, base: int = 32, zdim_dense: int = 128) -> dict:
     """Shape table of model/causal_netconfig.py:5-103 / model/net_config.py:5-103
     (they differ only in the encoder time padding: 1 causal, 0 otherwise).  ``base``
@@ -528,13 +547,21 @@ def standard_dccrn(x5, sd, pre, np_, causal, skip_to_use, train, bn_state=None):
 
 
 def dccrn_forward(signal, sd, np_, causal, n_fft, hop, win_length, skip_to_use, recon_type="mask",
-                  train=False, bn_state=None):
-    """DCCRN_.forward, model/pvae_module.py:215-255 (no data-norm, no resynthesis).
-    Returns (clean [B, L'], predict [B,F,T,2], latent)."""
+                  train=False, bn_state=None, data_mean=None, data_std=None):
+    """DCCRN_.forward, model/pvae_module.py:215-255 (no resynthesis).  data_mean / data_std [1, F, 1, 2]: the optional input
+    normalisation (:217-221: (stft - mean) / (std + 1e-6), imaginary parts of the first and last bin zeroed) and its inverse on
+    the prediction (:235-238, :246-247).  Returns (clean [B, L'], predict [B,F,T,2], latent)."""
     X = stft(signal, n_fft, hop, win_length)
+    if data_mean is not None:
+        X = (X - data_mean) / (data_std + 1e-6)
+        X = X.clone()
+        X[:, 0, :, 1] = 0
+        X[:, -1, :, 1] = 0
     out, latent = standard_dccrn(X.unsqueeze(1), sd, "std_DCCRN.", np_, causal, skip_to_use, train, bn_state)
     out = out.squeeze(1)
     pred = apply_mask(out, X) if recon_type == "mask" else out
+    if data_mean is not None:
+        pred = data_std * pred + data_mean
     return istft(pred, n_fft, hop, win_length), pred, latent
 
 

@@ -570,6 +570,25 @@ def gen_datanorm():
         clean, pred = m(x, train=False)
         out[f"clean_{rt}"] = clean
         out[f"pred_{rt}"] = torch.view_as_real(pred)
+        o_clean, o_pred, _ = O.dccrn_forward(x, sd, np_, True, NFFT, HOP, WIN, skip, rt, False, None, mean, std)
+        check(f"datanorm {rt} waveform", o_clean, clean, 1e-4)
+        check(f"datanorm {rt} predict", o_pred, torch.view_as_real(pred), 1e-4)
+    # the same model as a TRAIN step (the reference's loss.backward() with --data_norm): loss + parameter gradients
+    with torch.enable_grad():
+        m = R_pm.DCCRN_(NFFT, HOP, np_, True, "cpu", WIN, skip, "mask", False, mean, std)
+        sd = O.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items() if v is not None and k not in ("data_mean", "data_std")}, 94)
+        sd["data_mean"], sd["data_std"] = mean, std
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        fix_bn_flags(m, True)
+        clean_ref = rnd(95, 2, 1600, scale=0.1)
+        w = [0.2, 0.1, 1.0]
+        est, pred = m(x, train=True)
+        loss = R_nl.ete_train_se_loss(w).final_ete_loss(pred, m.stft(clean_ref), clean_ref, est)
+        loss[0].backward()
+    out.update(train_clean_ref=clean_ref, train_weights=np.asarray(w, dtype="float32"),
+               train_loss=torch.stack([v.detach() for v in loss]), train_est=est.detach())
+    grad_record(out, "train:", m)
     save("dccrn_datanorm_mini", **out)
 
 
@@ -656,10 +675,38 @@ def gen_evalpath():
     save("op_sisdr", est=est, ref=ref, sisdr=np.float64(want))
 
 
+def gen_resi():
+    """residual_loss of the REAL standard_nsvae_loss_true_kl (model/nsvae_loss.py:363-446) in its five modes."""
+    print("== residual (skip-matching) loss")
+    B, F, T = 2, 5, 7
+    chans = [4, 6, 8]
+    clean = [rnd(500 + i, B, c, F, T, 2) for i, c in enumerate(chans)]
+    noise = [rnd(510 + i, B, c, F, T, 2) for i, c in enumerate(chans)]
+    noisy1 = [rnd(520 + i, B, c, F, T, 2) for i, c in enumerate(chans)]          # same width as the clean encoder
+    noisy2 = [rnd(530 + i, B, 2 * c, F, T, 2) for i, c in enumerate(chans)]      # speech | noise halves
+    out = dict(chans=np.asarray(chans), skip_to_use=np.asarray([0, 2]))
+    for i in range(3):
+        out.update({f"clean{i}": clean[i], f"noise{i}": noise[i], f"noisy1_{i}": noisy1[i], f"noisy2_{i}": noisy2[i]})
+    modes = {"l1_plain": (1, "original", "speech", noisy1), "l1_split": (1, "adapt", "speech", noisy2),
+             "l2_both": (2, "original", "both", noisy2), "l2_speech_split": (2, "double", "speech", noisy2),
+             "l2_speech_plain": (2, "original", "speech", noisy1)}
+    for name, (latent_num, model, matching, noisy) in modes.items():
+        L_ = R_nl.standard_nsvae_loss_true_kl(1.0, 0.5, 1.0, 0.0, 16, 2, latent_num, model, "True", [0, 2], matching)
+        want = L_.residual_loss(clean, noise, noisy)
+        got = O.residual_loss(clean, noise, noisy, [0, 2], latent_num, model in ("adapt", "double"), matching)
+        for a, b in zip(got, want):
+            assert abs(float(a) - float(b)) <= 1e-6 * max(1.0, abs(float(b))), (name, float(a), float(b))
+        print(f"  [ok] oracle vs reference  residual_loss {name}: {[round(float(v), 6) for v in want]}")
+        out[name] = np.asarray([float(v) for v in want], dtype="float64")
+    save("op_resi", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "mini", "full"]
     if "evalpath" in which:
         gen_evalpath()
+    if "resi" in which:
+        gen_resi()
     if "ops" in which:
         gen_ops()
     if "mini" in which:
@@ -679,8 +726,9 @@ if __name__ == "__main__":
         # elements per tensor + full L2 norms
         torch.set_num_threads(os.cpu_count())
         gen_grad_dccrn("full", 32, 2, 16000, 91, [0.2, 0.1, 1.0], limit=2048, cap=1024, adam=False)
-    if "extras" in which:
+    if "extras" in which or "datanorm" in which:
         gen_datanorm()
+    if "extras" in which:
         gen_checkpoint()
     if "vaefull" in which:
         torch.set_num_threads(os.cpu_count())

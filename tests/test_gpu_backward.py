@@ -713,6 +713,31 @@ def test_end_to_end_encoder_decoder_grads_with_repeated_skips(pm, losses):
     assert n > 60
 
 
+def test_grad_dccrn_datanorm_reference(pm, losses, golden):
+    """Training WITH the reference's --data_norm (model/pvae_module.py:217-221, :235-238; VERDICT r2 'missing' 5b): the mini
+    DCCRN-CL train step against loss and parameter gradients written by the REAL reference (make_golden.py datanorm)."""
+    d = golden("dccrn_datanorm_mini")
+    nl, _, _ = losses
+    np_ = O.net_params(True, 4)
+    mean, std = T_(d["data_mean"]), T_(d["data_std"])
+    m = pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, mean, std)
+    sd = O.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items() if k not in ("data_mean", "data_std")}, int(d["seed"]))
+    sd["data_mean"], sd["data_std"] = mean, std
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    m.train()
+    x, clean_ref = T_(d["x"]).cuda(), T_(d["train_clean_ref"]).cuda()
+    w = [float(v) for v in d["train_weights"]]
+    with torch.enable_grad():
+        est, pred = m(x, train=True)
+        loss = nl.ete_train_se_loss(w).final_ete_loss(pred, m.stft(clean_ref), clean_ref, est)
+        loss[0].backward()
+    assert relerr(est.detach().cpu(), T_(d["train_est"])) < 1e-4
+    for a, b in zip(loss, T_(d["train_loss"])):
+        assert abs(float(a) - float(b)) < 2e-4 * max(1.0, abs(float(b)))
+    print("worst parameter-gradient error", check_grads(d, "train:", m))
+
+
 def test_noncausal_dccrn_train_step_grads(pm, losses):
     """The non-causal DCCRN (model/net_config.py; VERDICT r2 'missing' 5a) as a TRAIN step: forward(train=True) + final_ete_loss +
     backward through the HIP autograd path against torch.autograd through the oracle in float64 -- loss, input gradient and every

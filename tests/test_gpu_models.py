@@ -366,6 +366,57 @@ def test_nsvae_loss_from_encoders(pm, losses):
         assert abs(float(a) - float(b)) < 2e-4 * max(1.0, abs(float(b)))
 
 
+RESI_MODES = {"l1_plain": (1, "original", "speech", "noisy1"), "l1_split": (1, "adapt", "speech", "noisy2"),
+              "l2_both": (2, "original", "both", "noisy2"), "l2_speech_split": (2, "double", "speech", "noisy2"),
+              "l2_speech_plain": (2, "original", "speech", "noisy1")}
+
+
+@pytest.mark.parametrize("mode", sorted(RESI_MODES))
+def test_residual_loss_golden(losses, golden, mode):
+    """standard_nsvae_loss_true_kl.residual_loss (model/nsvae_loss.py:363-446; idv_msd) against the reference class's own
+    values on the fixture's skip lists, all five (latent_num, skiper_split, matching) modes."""
+    nl, _ = losses
+    d = golden("op_resi")
+    key = lambda k, i: f"{k}{'_' if k.startswith('noisy') else ''}{i}"
+    lists = {k: [torch.from_numpy(d[key(k, i)]).cuda() for i in range(3)] for k in ("clean", "noise", "noisy1", "noisy2")}
+    latent_num, model, matching, noisy = RESI_MODES[mode]
+    loss = nl.standard_nsvae_loss_true_kl(1.0, 0.5, 1.0, 0.0, 16, 2, latent_num, model, "True", [int(v) for v in d["skip_to_use"]],
+                                          matching)
+    got = loss.residual_loss(lists["clean"], lists["noise"], lists[noisy])
+    for a, b in zip(got, d[mode]):
+        assert abs(float(a) - float(b)) <= 2e-6 * max(1.0, abs(float(b))), (mode, float(a), float(b))
+    if mode == "l1_plain":                                            # the reference's own shape error, not a silent slice
+        with pytest.raises(RuntimeError):
+            loss.residual_loss(lists["clean"], lists["noise"], lists["noisy2"])
+
+
+def test_nsvae_residual_loss_from_encoders(pm, losses):
+    """config 3 with skipc 'True' and w_resi != 0 (train_nsvae.py:487-544): the residual term on the three encoders' own skip
+    lists (planar activations attached, no conversion) - reported next to the loss and, as in the reference (:460-466), not
+    part of it."""
+    nl, _ = losses
+    base, zdim, ns = 4, 16, 2
+    np_ = O.net_params(True, base)
+    ce = load_synth(pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns), 61)
+    ne = load_synth(pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns), 62)
+    se = load_synth(pm.nsvae_pvae_dccrn_encoder_twophase(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns, 2), 63)
+    g = torch.Generator().manual_seed(3)
+    clean, noise = torch.randn(2, 1600, generator=g) * 0.1, torch.randn(2, 1600, generator=g) * 0.1
+    c = ce(clean.cuda(), train=False)
+    n = ne(noise.cuda(), train=False)
+    s = se((clean + noise).cuda(), train=True)
+    args = (c[1], n[1], s[1], s[5], c[2], n[2], s[2], s[6], c[3], n[3], s[3], s[7], s[0], s[4], c[4], n[4], s[8])
+    plain = nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.5, zdim, ns, 2, 'original', 'True', SKIP, 'speech')
+    with_resi = nl.standard_nsvae_loss_true_kl(1.0, 0.7, 1.0, 0.5, zdim, ns, 2, 'original', 'True', SKIP, 'speech')
+    a, b = plain.final_nsvae_loss(*args), with_resi.final_nsvae_loss(*args)
+    assert float(a[0]) == float(b[0]) and tuple(float(v) for v in a[6:]) == (0.0, 0.0, 0.0)
+    cpu = lambda lst: [t.detach().cpu() for t in lst]
+    want = O.residual_loss(cpu(c[4]), cpu(n[4]), cpu(s[8]), SKIP, 2, False, 'speech')
+    assert float(want[0]) > 0
+    for x, y in zip(b[6:], want):
+        assert abs(float(x) - float(y)) <= 1e-5 * max(1.0, abs(float(y)))
+
+
 def test_state_dict_roundtrip_and_repack(pm):
     """Weights are re-packed when parameters change in place (optimizer step / load_state_dict)."""
     np_ = O.net_params(True, 4)

@@ -224,3 +224,22 @@ def test_evalpath_estimators_and_sisdr_golden(golden):
         assert float((got - want).norm() / want.norm()) < 1e-6, name
     s = golden("op_sisdr")
     assert abs(float(O.sisdr_np(s["est"], s["ref"])) - float(s["sisdr"])) < 1e-5
+
+
+RESI_MODES = {"l1_plain": (1, False, "speech", "noisy1"), "l1_split": (1, True, "speech", "noisy2"),
+              "l2_both": (2, False, "both", "noisy2"), "l2_speech_split": (2, True, "speech", "noisy2"),
+              "l2_speech_plain": (2, False, "speech", "noisy1")}
+
+
+def test_residual_loss_golden(golden):
+    """The skip-matching term (model/nsvae_loss.py:363-446) in its five modes against the reference class's own values
+    (tests/golden/make_golden.py resi)."""
+    d = golden("op_resi")
+    use = [int(v) for v in d["skip_to_use"]]
+    lists = {k: [torch.from_numpy(d[f"{k}{'_' if k.startswith('noisy') else ''}{i}"]) for i in range(3)]
+             for k in ("clean", "noise", "noisy1", "noisy2")}
+    for name, (latent_num, split, matching, noisy) in RESI_MODES.items():
+        got = O.residual_loss(lists["clean"], lists["noise"], lists[noisy], use, latent_num, split, matching)
+        for a, b in zip(got, d[name]):
+            assert abs(float(a) - float(b)) <= 1e-6 * max(1.0, abs(float(b))), name
+
