@@ -727,6 +727,27 @@ class CklFn(torch.autograd.Function):
         return None, None, None, None, None, None, dq1, None
 
 
+class MiFn(torch.autograd.Function):
+    """mutual_information (pretrain_pvaes_loss.py:129-159): gradient to the posterior (miu, log_sigma, delta) and to the samples."""
+
+    @staticmethod
+    def forward(ctx, glat, off, gz, zdim, ns, eps, latbuf, zbuf):
+        out, work = ops.mi_estimate(_mk(latbuf, glat), off, _mk(zbuf, gz), zdim, ns, eps)
+        ctx.save_for_backward(latbuf, zbuf, work)
+        ctx.args = (glat, off, gz, zdim, ns, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        latbuf, zbuf, work = ctx.saved_tensors
+        glat, off, gz, zdim, ns, eps = ctx.args
+        dlat = torch.zeros_like(latbuf) if ctx.needs_input_grad[6] else None
+        dz = torch.zeros_like(zbuf) if ctx.needs_input_grad[7] else None
+        ops.mi_bwd(_mk(latbuf, glat), off, _mk(zbuf, gz), zdim, ns, eps, work, g.contiguous().float(),
+                   _mk(dlat, glat) if dlat is not None else None, _mk(dz, gz) if dz is not None else None)
+        return None, None, None, None, None, None, dlat, dz
+
+
 class MiuDistFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g1, off1, g2, off2, zdim, q1buf, q2buf):

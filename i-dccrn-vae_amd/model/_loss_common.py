@@ -10,7 +10,7 @@ from ..ops import Planar
 from .sisnr_loss import si_snr
 
 
-def latent_ref(miu, log_sigma, delta):
+def latent_ref(miu, log_sigma, delta, Tp=None):
     """(planar latent, (off_miu, off_log_sigma, off_delta)) for three [B, T, H, 2] tensors.  Views handed out
     by the encoders share one planar LSTM output and cost nothing; foreign tensors are packed once."""
     pls = [getattr(t, "_idv", None) for t in (miu, log_sigma, delta)]
@@ -20,13 +20,13 @@ def latent_ref(miu, log_sigma, delta):
         raise RuntimeError("i-dccrn-vae_amd runs on the MI355X only: pass CUDA (ROCm) tensors")
     H = miu.shape[2]
     lat = torch.cat([miu, log_sigma, delta], dim=2).permute(0, 2, 1, 3).unsqueeze(2)
-    return Planar.from_tensor5(lat.float()), (0, H, 2 * H)
+    return Planar.from_tensor5(lat.float(), Tp), (0, H, 2 * H)
 
 
 def kl_mean(q1, q2, zdim: int, eps: float) -> torch.Tensor:
     """mean over (b, t) of KL(q1 || q2); q = (miu, log_sigma, delta); q2 None = prior (0, 0, 0)."""
     p1, o1 = latent_ref(*q1)
-    p2, o2 = (None, None) if q2 is None else latent_ref(*q2)
+    p2, o2 = (None, None) if q2 is None else latent_ref(*q2, Tp=p1.Tp)
     if p2 is not None and (p1.B, p1.T, p1.Tp) != (p2.B, p2.T, p2.Tp):
         raise RuntimeError("KL operands must share batch and frame counts")
     if AG.grad_mode(p1.buf, p2.buf if p2 is not None else None):
@@ -35,7 +35,7 @@ def kl_mean(q1, q2, zdim: int, eps: float) -> torch.Tensor:
     return ops.ckl(p1, o1, p2, o2, zdim, eps)
 
 
-def recon_terms(predict_cpx_stft, ori_cpx_stft, source, est_source, weights):
+def recon_terms(predict_cpx_stft, ori_cpx_stft, source, est_source, weights, with_sisnr: bool = True):
     """multiple_recon_loss of the reference (nsvae_loss.py:775-797 and copies): (final, cpx, mag, sisnr)."""
     pc = predict_cpx_stft
     if not torch.view_as_real(pc).is_contiguous():
@@ -48,6 +48,8 @@ def recon_terms(predict_cpx_stft, ori_cpx_stft, source, est_source, weights):
         loss_cpx, loss_mag = AG.ReconLossFn.apply(torch.view_as_real(pc), ori_cpx_stft.detach().float(), div)
     else:
         loss_cpx, loss_mag = ops.recon_loss(pc, ori_cpx_stft.float(), div)
+    if not with_sisnr:
+        return weights[0] * loss_cpx + weights[1] * loss_mag, loss_cpx, loss_mag, None
     sisnr = si_snr(source, est_source)
     final = weights[0] * loss_cpx + weights[1] * loss_mag + weights[2] * sisnr
     return final, loss_cpx, loss_mag, sisnr

@@ -767,6 +767,26 @@ def ckl(q1: Planar, off1, q2: Optional[Planar], off2, zdim: int, eps: float) -> 
     return out[0]
 
 
+def mi_estimate(lat: Planar, off, z: Planar, zdim: int, ns: int, eps: float):
+    """Minibatch mutual information (pretrain_pvaes_loss.py:129-159) -> (scalar, work); `work` holds d MI / d log q for mi_bwd."""
+    lib = L.lib()
+    lib.idv_mi_work_floats.restype = L._L
+    if (z.C, z.B, z.T, z.Tp) != (zdim, lat.B * ns, lat.T, lat.Tp):
+        raise ValueError(f"mutual_information: samples {(z.C, z.B, z.T)} do not belong to a posterior {(zdim, lat.B, lat.T)} x {ns}")
+    work = torch.empty(int(lib.idv_mi_work_floats(i(lat.B), i(ns), i(lat.T), i(zdim))), dtype=torch.float32, device=lat.buf.device)
+    acc = torch.empty(1, dtype=torch.float64, device=lat.buf.device)
+    out = torch.empty(1, dtype=torch.float32, device=lat.buf.device)
+    call("idv_mi_fwd", lat.ptr(), i(lat.C), i(lat.Jp), i(off[0]), i(off[1]), i(off[2]), z.ptr(), i(z.Jp), i(zdim), i(ns), i(lat.B),
+         i(lat.T), i(lat.Tp), f(eps), p(work), p(acc), p(out), stream_ptr())
+    return out[0], work
+
+
+def mi_bwd(lat: Planar, off, z: Planar, zdim: int, ns: int, eps: float, work, gout, dlat: Optional[Planar], dz: Optional[Planar]):
+    call("idv_mi_bwd", lat.ptr(), i(lat.C), i(lat.Jp), i(off[0]), i(off[1]), i(off[2]), z.ptr(), i(z.Jp), i(zdim), i(ns), i(lat.B),
+         i(lat.T), i(lat.Tp), f(eps), p(work), p(gout), dlat.ptr() if dlat is not None else p(None),
+         dz.ptr() if dz is not None else p(None), stream_ptr())
+
+
 def miu_dist(q1: Planar, off1: int, q2: Planar, off2: int, zdim: int) -> torch.Tensor:
     work = torch.empty(3 * 2 * zdim, dtype=torch.float64, device=q1.buf.device)
     out = torch.empty(1, dtype=torch.float32, device=q1.buf.device)

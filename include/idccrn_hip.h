@@ -360,6 +360,18 @@ int idv_ckl(const float* q1, int H1, int Jp1, int o1_miu, int o1_ls, int o1_dl, 
  * work: 3 doubles. */
 int idv_msd(const float* a, int Ca, int ca0, int JpA, const float* b, int Cb, int cb0, int JpB, int C, int F, int B, int Tp,
             int t_valid, double* work, float* out, void* stream);
+/* Minibatch mutual-information estimate of the CVAE / NVAE ELBO (complex_standard_vae_loss.mutual_information,
+ * model/pretrain_pvaes_loss.py:129-159 on cal_gaussian_prob :64-127; the "- mi_weight * mi" term of cal_loss :334-343):
+ * mean over (i, s, t) of log q(z[i,s,t] | x_i) - (logsumexp_j log q(z[i,s,t] | x_j) - log B).
+ * lat: planar posterior [2][H][Jp] with (miu, log_sigma, delta) at channel offsets (column b*Tp + t + 1); z: the planar samples
+ * [2][zdim][Jpz] of idv_reparam (column (b*ns + s)*Tp + t + 1).  work: idv_mi_work_floats floats, kept for idv_mi_bwd (it holds
+ * d MI / d log q afterwards); acc: 1 double.  idv_mi_bwd: dz (same shape as z, written) and dlat (same shape as lat, += on the
+ * three channel groups), each scaled by gout[0]; either may be NULL. */
+long long idv_mi_work_floats(int B, int ns, int T, int zdim);
+int idv_mi_fwd(const float* lat, int H, int Jp, int o_miu, int o_ls, int o_dl, const float* z, int Jpz, int zdim, int ns, int B,
+               int T, int Tp, float eps, float* work, double* acc, float* out, void* stream);
+int idv_mi_bwd(const float* lat, int H, int Jp, int o_miu, int o_ls, int o_dl, const float* z, int Jpz, int zdim, int ns, int B,
+               int T, int Tp, float eps, const float* work, const float* gout, float* dlat, float* dz, void* stream);
 /* miu_dis_loss term (model/nsvae_loss.py:349-360): sqrt(sum_{h,ri} mean_{b,t} (miu1 - miu2)^2). */
 int idv_miu_dist(const float* q1, int H1, int Jp1, int off1, const float* q2, int H2, int Jp2, int off2, int zdim,
                  int B, int T, int Tp, double* work, float* out, void* stream);

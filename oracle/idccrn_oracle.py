@@ -357,6 +357,59 @@ def cvae_elbo(source, est, stft_source, pred_ri, miu, log_sigma, delta, kl_weigh
     return recon + kl_weight * kl, recon, kl, l_cpx, l_mag, l_snr
 
 
+def gaussian_logprob(miu, log_sigma, delta, z, eps: float = 1e-9) -> Tensor:
+    """complex_standard_vae_loss.cal_gaussian_prob, model/pretrain_pvaes_loss.py:64-127: log q(z | miu, sigma, delta) of the
+    improper complex Gaussian per (posterior b, sample s, frame t); miu / log_sigma / delta [B, T, H, 2], z [B or 1, S, T, H, 2]
+    (broadcast over the posterior axis) -> [B, S, T].  Note the guard scales to 0.90 sigma here (0.99 in the KL)."""
+    u = lambda v: v.unsqueeze(1)
+    sg = u(torch.exp(log_sigma[..., 0]))
+    dr, di = u(delta[..., 0]), u(delta[..., 1])
+    a = torch.sqrt(dr * dr + di * di + eps)
+    scale = sg * 0.90 / (a + eps)
+    hit = a >= (sg - 1e-3)
+    dr, di = torch.where(hit, dr * scale, dr), torch.where(hit, di * scale, di)
+    q = dr * dr + di * di
+    P = sg - q / (sg + eps)
+    rp = 1 / (P + eps)
+    Rr = dr / (sg * P + eps)
+    Ri = -di / (sg * P + eps)
+    m = rp - q / (sg * P * sg + eps)
+    logs = torch.sum(torch.log(m + eps), dim=3) + torch.sum(torch.log(rp + eps), dim=3)
+    xr, xi = z[..., 0] - u(miu[..., 0]), z[..., 1] - u(miu[..., 1])
+    quad = torch.sum((xr * xr - xi * xi) * Rr - 2 * xr * xi * Ri, dim=3) - torch.sum((xr * xr + xi * xi) * rp, dim=3)
+    return 0.5 * logs + quad
+
+
+def mutual_information(miu, log_sigma, delta, z, num_samples: int, eps: float = 1e-9) -> Tensor:
+    """complex_standard_vae_loss.mutual_information, model/pretrain_pvaes_loss.py:129-159: the minibatch estimate of I(x; z),
+    mean over (i, s, t) of log q(z_ist | x_i) - (logsumexp_j log q(z_ist | x_j) - log B); z [B * num_samples, T, H, 2]."""
+    B, T, H, D = miu.shape
+    z = z.view(B, num_samples, T, H, D)
+    log_q_zx = gaussian_logprob(miu, log_sigma, delta, z, eps)
+    log_q_z = torch.stack([torch.logsumexp(gaussian_logprob(miu, log_sigma, delta, z[i].unsqueeze(0), eps), dim=0)
+                           - torch.log(torch.tensor(float(B))) for i in range(B)])
+    return torch.mean(log_q_zx - log_q_z)
+
+
+def cvae_elbo_full(source, est, stft_source, pred_ri, miu, log_sigma, delta, z, kl_weight: float, mi_weight: float,
+                   recon_loss_type: str, weights: Sequence[float], num_samples: int, prior_mode: str):
+    """complex_standard_vae_loss.cal_loss with all its branches (model/pretrain_pvaes_loss.py:313-347): recon 'multiple' | 'prob'
+    (:161-182), prior 'ri_inde' | 'ri_corr' (:322-331), minus mi_weight x the mutual-information estimate (:334-343)."""
+    if recon_loss_type == "multiple":
+        recon, l_cpx, l_mag, l_snr = multiple_recon_loss(pred_ri, stft_source, source, est, weights)
+    else:
+        d = (pred_ri[..., 0] - stft_source[..., 0]) ** 2 + (pred_ri[..., 1] - stft_source[..., 1]) ** 2
+        recon = torch.sum(d, dim=1).mean()
+        l_cpx = l_mag = l_snr = torch.tensor(0)
+    zz = torch.zeros_like
+    d_prior = zz(delta)
+    if prior_mode == "ri_corr":
+        d_prior[..., 1] = 1
+    kl = complex_kl(miu, zz(miu), log_sigma, zz(log_sigma), delta, d_prior, 1e-9).mean()
+    mi = mutual_information(miu, log_sigma, delta, z, num_samples) if mi_weight != 0 else torch.tensor(0)
+    return recon + kl_weight * kl - mi_weight * mi, recon, kl, mi, l_cpx, l_mag, l_snr
+
+
 def nsvae_loss(mc, mn, ms, mnn, lc, ln, ls, lnn, dc, dn, ds, dnn, alpha, w_kl, w_dismiu, latent_num=2):
     """standard_nsvae_loss_true_kl.final_nsvae_loss with w_resi=0
     (model/nsvae_loss.py:330-360, :448-473).  c=clean, n=noise, s=noisy-speech, nn=noisy-noise."""

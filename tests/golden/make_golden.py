@@ -488,6 +488,41 @@ def gen_grad_vae(tag, base, zdim, B, L, ns, seed):
     save(f"grad_twophase_{tag}", **out)
 
 
+def gen_grad_cvae_mi(tag, base, zdim, B, L, ns, seed, mi_weight=2.0):
+    """The CVAE pre-training step of gen_grad_vae with the mutual-information term on (pretrained_vaes/train.py --mi_weight;
+    pretrain_pvaes_loss.py:334-343): loss values and the ENCODER's gradients (the decoder's do not see the term)."""
+    print(f"== grads CVAE + MI {tag}: mi_weight={mi_weight}")
+    np_ = O.net_params(True, base)
+    T = 1 + L // HOP
+    orig = torch.randn_like
+    w = [0.01, 0.01, 0.0]            # small reconstruction weights: the KL and MI terms carry a visible share of the gradient
+    with torch.enable_grad():
+        enc = R_pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cpu", zdim, NFFT, HOP, WIN, ns)
+        dec = R_pm.pvae_dccrn_decoder_skip_prepare(np_, True, "cpu", ns, zdim, NFFT, HOP, WIN, "real_imag", [0, 1, 2, 3, 4, 5])
+        load_synth(enc, seed), load_synth(dec, seed + 1)
+        enc.train(), dec.train()
+        fix_bn_flags(enc, True), fix_bn_flags(dec, True)
+        x = rnd(seed + 100, B, L, scale=0.1)
+        eps = [rnd(seed + 300, B, ns, T, zdim), rnd(seed + 301, B, ns, T, zdim)]
+        draws = list(eps)
+        torch.randn_like = lambda t, *a, **k: draws.pop(0)
+        try:
+            z, miu, ls, dl, skiper, C, F, stft_x = enc(x, train=True)
+        finally:
+            torch.randn_like = orig
+        recon, pred = dec(stft_x, z, skiper, C, F, train=True)
+        xr = x.unsqueeze(1).repeat(1, ns, 1).view(B * ns, L)
+        sx = stft_x.unsqueeze(1).repeat(1, ns, 1, 1, 1).view(B * ns, stft_x.shape[1], stft_x.shape[2], 2)
+        pl = R_pl.complex_standard_vae_loss(torch.ones(1), 1.0, mi_weight, 'multiple', 'real_imag', w, ns)
+        lo = pl.cal_loss(xr, recon, sx, pred, miu, ls, dl, z, 5)
+        lo[0].backward()
+    out = dict(x=x, eps_r=eps[0], eps_i=eps[1], seed=seed, base=base, zdim=zdim, ns=ns, weights=np.asarray(w, dtype="float32"),
+               mi_weight=np.asarray(mi_weight), loss=torch.stack([torch.as_tensor(v).detach().float() for v in lo]))
+    print(f"  final {float(lo[0]):.5f} kl {float(lo[2]):.5f} mi {float(lo[3]):.5f}")
+    grad_record(out, "enc.", enc)
+    save(f"grad_cvae_mi_{tag}", **out)
+
+
 def sub(t, *steps):
     idx = tuple(slice(None, None, s) for s in steps)
     return t[idx].clone()
@@ -701,12 +736,70 @@ def gen_resi():
     save("op_resi", **out)
 
 
+@torch.enable_grad()
+def gen_mi():
+    """mutual_information / cal_gaussian_prob / the 'prob' and 'ri_corr' branches of the REAL complex_standard_vae_loss
+    (model/pretrain_pvaes_loss.py:64-182, :313-347), values and autograd gradients."""
+    print("== CVAE ELBO: mutual information, prob recon, ri_corr prior")
+    B, ns, T, H, F = 3, 2, 5, 6, 7
+    miu = rnd(600, B, T, H, 2) * 0.5
+    log_sigma = rnd(601, B, T, H, 2) * 0.3
+    delta = rnd(602, B, T, H, 2) * 0.3
+    delta[0, 0, :2] = torch.tensor([1.4, -0.9])                       # |delta| > sigma: the 0.90 guard fires
+    eps_r, eps_i = rnd(603, B, ns, T, H), rnd(604, B, ns, T, H)
+    z = O.reparameterization(miu, log_sigma, delta, ns, eps_r, eps_i)
+    z = z + 0.3 * rnd(605, *z.shape)
+    out = dict(miu=miu, log_sigma=log_sigma, delta=delta, z=z, ns=np.asarray(ns))
+    leaves = [t.clone().requires_grad_(True) for t in (miu, log_sigma, delta, z)]
+    pl = R_pl.complex_standard_vae_loss(torch.ones(1), 1.0, 0.7, 'multiple', 'real_imag', [1, 1, 0], ns)
+    lp = pl.cal_gaussian_prob(miu, log_sigma, delta, z.view(B, ns, T, H, 2))
+    check("gaussian_logprob", O.gaussian_logprob(miu, log_sigma, delta, z.view(B, ns, T, H, 2)), lp, 1e-5)
+    mi = pl.mutual_information(*leaves)
+    grads = torch.autograd.grad(mi, leaves)
+    oleaves = [t.clone().requires_grad_(True) for t in (miu, log_sigma, delta, z)]
+    omi = O.mutual_information(*oleaves, ns)
+    ograds = torch.autograd.grad(omi, oleaves)
+    assert abs(float(omi) - float(mi)) < 1e-5 * max(1.0, abs(float(mi)))
+    for n, a, b in zip(("miu", "log_sigma", "delta", "z"), ograds, grads):
+        check(f"mutual_information d/d{n}", a, b, 1e-4)
+        out[f"g_{n}"] = b
+    out["mi"] = np.asarray(float(mi))
+    out["logprob"] = lp
+    print(f"  mutual information {float(mi):.6f}")
+    # cal_loss in the four (recon, prior) branches with the MI term on
+    src, est = rnd(610, B * ns, 400) * 0.1, rnd(611, B * ns, 400) * 0.1
+    stft_src = rnd(612, B, F, T, 2)
+    pred = torch.view_as_complex(rnd(613, B * ns, F, T, 2).contiguous())
+    out.update(source=src, est=est, stft_source=stft_src, pred=torch.view_as_real(pred))
+    stft_rep = stft_src.repeat_interleave(ns, dim=0)
+    for recon in ("multiple", "prob"):
+        for prior in ("ri_inde", "ri_corr"):
+            pl = R_pl.complex_standard_vae_loss(torch.ones(1), 0.8, 0.7, recon, 'real_imag', [1.0, 0.5, 0.25], ns, prior)
+            leaves = [t.clone().requires_grad_(True) for t in (miu, log_sigma, delta, z)]
+            res = pl.cal_loss(src, est, stft_rep, pred, *leaves, 5)
+            want = [float(v) for v in res]
+            got = O.cvae_elbo_full(src, est, stft_rep, torch.view_as_real(pred), miu, log_sigma, delta, z, 0.8, 0.7, recon,
+                                   [1.0, 0.5, 0.25], ns, prior)
+            order = (0, 1, 2, 3, 4, 5, 6)
+            for k in order:
+                assert abs(float(got[k]) - want[k]) <= 2e-5 * max(1.0, abs(want[k])), (recon, prior, k, float(got[k]), want[k])
+            g = torch.autograd.grad(res[0], leaves)
+            out[f"loss:{recon}:{prior}"] = np.asarray(want, dtype="float64")
+            for n, t in zip(("miu", "log_sigma", "delta", "z"), g):
+                out[f"g:{recon}:{prior}:{n}"] = t
+            print(f"  [ok] oracle vs reference  cal_loss {recon}/{prior}: final {want[0]:.6f} kl {want[2]:.6f} mi {want[3]:.6f}")
+    save("op_mi", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "mini", "full"]
     if "evalpath" in which:
         gen_evalpath()
     if "resi" in which:
         gen_resi()
+    if "mi" in which:
+        gen_mi()
+        gen_grad_cvae_mi("mini", 4, 32, 3, 1600, 2, 71)
     if "ops" in which:
         gen_ops()
     if "mini" in which:

@@ -897,3 +897,76 @@ YARD = {"fp32": (5.0, 1e-3, 3.0), "bf16x3": (15.0, 6e-3, 10.0)}
 def ops_precision():
     import importlib
     return importlib.import_module("i-dccrn-vae_amd").ops.PRECISION
+
+
+def _mi_fixture(golden):
+    d = golden("op_mi")
+    return d, (lambda k: torch.from_numpy(d[k]).cuda()), int(d["ns"])
+
+
+def test_mutual_information_reference(golden):
+    """complex_standard_vae_loss.mutual_information (model/pretrain_pvaes_loss.py:129-159; idv_mi_fwd / idv_mi_bwd): value and
+    the gradients to miu, log_sigma, delta and the samples against the reference class's autograd (fixture op_mi.npz; two
+    components sit inside the |delta| >= sigma guard)."""
+    pl = importlib.import_module("i-dccrn-vae_amd.model.pretrain_pvaes_loss")
+    d, T_, ns = _mi_fixture(golden)
+    loss = pl.complex_standard_vae_loss(torch.ones(1), 1.0, 0.7, 'multiple', 'real_imag', [1, 1, 0], ns)
+    with torch.no_grad():
+        assert abs(float(loss.mutual_information(T_("miu"), T_("log_sigma"), T_("delta"), T_("z"))) - float(d["mi"])) < 2e-5
+    leaves = [T_(k).requires_grad_(True) for k in ("miu", "log_sigma", "delta", "z")]
+    mi = loss.mutual_information(*leaves)
+    assert abs(float(mi.detach()) - float(d["mi"])) < 2e-5
+    (3.0 * mi).backward()
+    for n, t in zip(("miu", "log_sigma", "delta", "z"), leaves):
+        e = relerr(t.grad.cpu() / 3.0, torch.from_numpy(d[f"g_{n}"]))
+        assert e < 2e-4, (n, e)
+
+
+@pytest.mark.parametrize("recon", ["multiple", "prob"])
+@pytest.mark.parametrize("prior", ["ri_inde", "ri_corr"])
+def test_elbo_branches_reference(golden, recon, prior):
+    """cal_loss (model/pretrain_pvaes_loss.py:313-347) with mi_weight 0.7 in the four (recon_loss_type, prior_mode) branches:
+    the seven returned values and the gradients of the final loss to the posterior and the samples, against the reference."""
+    pl = importlib.import_module("i-dccrn-vae_amd.model.pretrain_pvaes_loss")
+    d, T_, ns = _mi_fixture(golden)
+    loss = pl.complex_standard_vae_loss(torch.ones(1), 0.8, 0.7, recon, 'real_imag', [1.0, 0.5, 0.25], ns, prior)
+    leaves = [T_(k).requires_grad_(True) for k in ("miu", "log_sigma", "delta", "z")]
+    stft_rep = T_("stft_source").repeat_interleave(ns, dim=0)
+    pred = torch.view_as_complex(T_("pred").contiguous())
+    res = loss.cal_loss(T_("source"), T_("est"), stft_rep, pred, *leaves, 5)
+    want = d[f"loss:{recon}:{prior}"]
+    for k, (a, b) in enumerate(zip(res, want)):
+        assert abs(float(a) - float(b)) <= 1e-4 * max(1.0, abs(float(b))), (k, float(a), float(b))
+    res[0].backward()
+    for n, t in zip(("miu", "log_sigma", "delta", "z"), leaves):
+        e = relerr(t.grad.cpu(), torch.from_numpy(d[f"g:{recon}:{prior}:{n}"]))
+        assert e < 5e-4, (n, e)
+
+
+def test_grad_cvae_mi_reference(pm, losses, golden):
+    """pretrained_vaes/train.py with --mi_weight != 0: the CVAE step of test_grad_cvae_reference with the mutual-information
+    term on (pretrain_pvaes_loss.py:334-343), on the encoder's own planar posterior and samples; the seven returned values and
+    the encoder's gradients against the reference (fixture grad_cvae_mi_mini.npz: reconstruction weights 0.01 so that the KL
+    and MI terms carry a visible share of the gradient)."""
+    d = golden("grad_cvae_mi_mini")
+    _, plm, _ = losses
+    base, seed, zdim, ns = int(d["base"]), int(d["seed"]), int(d["zdim"]), int(d["ns"])
+    np_ = O.net_params(True, base)
+    enc = load_synth(pm.pvae_dccrn_encoder_skip_prepare(np_, True, "cuda", zdim, NFFT, HOP, WIN, ns), seed)
+    dec = load_synth(pm.pvae_dccrn_decoder_skip_prepare(np_, True, "cuda", ns, zdim, NFFT, HOP, WIN, "real_imag", SKIP), seed + 1)
+    x = T_(d["x"]).cuda()
+    B, L = x.shape
+    eps = (T_(d["eps_r"]).cuda(), T_(d["eps_i"]).cuda())
+    w = [float(v) for v in d["weights"]]
+    with torch.enable_grad():
+        z, miu, ls, dl, skiper, C, F, stft_x = enc(x, train=True, eps=eps)
+        recon, pred = dec(stft_x, z, skiper, C, F, train=True)
+        xr = x.unsqueeze(1).repeat(1, ns, 1).view(B * ns, L)
+        sx = stft_x.detach().unsqueeze(1).repeat(1, ns, 1, 1, 1).view(B * ns, stft_x.shape[1], stft_x.shape[2], 2)
+        pl = plm.complex_standard_vae_loss(torch.ones(1), 1.0, float(d["mi_weight"]), 'multiple', 'real_imag', w, ns)
+        lo = pl.cal_loss(xr, recon, sx, pred, miu, ls, dl, z, 5)
+        lo[0].backward()
+    for k, (a, b) in enumerate(zip(lo, T_(d["loss"]))):
+        assert abs(float(a.detach()) - float(b)) < 3e-4 * max(1.0, abs(float(b))), (k, float(a.detach()), float(b))
+    print("worst", check_grads(d, "enc.", enc))
+

@@ -243,3 +243,29 @@ def test_residual_loss_golden(golden):
         for a, b in zip(got, d[name]):
             assert abs(float(a) - float(b)) <= 1e-6 * max(1.0, abs(float(b))), name
 
+
+def test_mutual_information_and_elbo_branches_golden(golden):
+    """complex_standard_vae_loss's off-recipe branches (model/pretrain_pvaes_loss.py:64-182, :313-347): cal_gaussian_prob,
+    mutual_information (value and gradients), and cal_loss in the (recon, prior) combinations with mi_weight 0.7 - against the
+    reference class's own outputs (tests/golden/make_golden.py mi)."""
+    d = golden("op_mi")
+    T_ = lambda k: torch.from_numpy(d[k])
+    ns = int(d["ns"])
+    miu, ls, dl, z = T_("miu"), T_("log_sigma"), T_("delta"), T_("z")
+    B, T, H, _ = miu.shape
+    assert relerr(O.gaussian_logprob(miu, ls, dl, z.view(B, ns, T, H, 2)), T_("logprob")) < 1e-5
+    leaves = [t.clone().requires_grad_(True) for t in (miu, ls, dl, z)]
+    with torch.enable_grad():
+        mi = O.mutual_information(*leaves, ns)
+        grads = torch.autograd.grad(mi, leaves)
+    assert abs(float(mi) - float(d["mi"])) < 1e-5
+    for n, g in zip(("miu", "log_sigma", "delta", "z"), grads):
+        assert relerr(g, T_(f"g_{n}")) < 1e-4, n
+    stft_rep = T_("stft_source").repeat_interleave(ns, dim=0)
+    for recon in ("multiple", "prob"):
+        for prior in ("ri_inde", "ri_corr"):
+            got = O.cvae_elbo_full(T_("source"), T_("est"), stft_rep, T_("pred"), miu, ls, dl, z, 0.8, 0.7, recon, [1.0, 0.5, 0.25],
+                                   ns, prior)
+            for a, b in zip(got, d[f"loss:{recon}:{prior}"]):
+                assert abs(float(a) - float(b)) <= 2e-5 * max(1.0, abs(float(b))), (recon, prior)
+
