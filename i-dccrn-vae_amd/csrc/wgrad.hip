@@ -60,10 +60,19 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
     const float* __restrict__ Sg = prod == 0 ? a.S : (prod == 1 ? a.S1 : a.S2);
     const float* __restrict__ Lg = prod == 0 ? a.L : (prod == 1 ? a.L1 : a.L2);
     const int sp0 = ts * MS, lp0 = tl * ML;
-    const int jt0 = split * a.jt_per_split;
-    int jt1 = jt0 + a.jt_per_split;
-    if (jt1 > a.jtiles) jt1 = a.jtiles;
-    const int nsteps = (jt1 > jt0) ? (jt1 - jt0) * a.Fs : 0;
+    // this split's range of the flattened (column tile, frequency row) step sequence
+    int g0, nsteps;
+    if (a.nsplit_bal > 0) {
+        const long long s0 = (long long)split * a.steps_total / a.nsplit_bal, s1 = (long long)(split + 1) * a.steps_total / a.nsplit_bal;
+        g0 = (int)s0;
+        nsteps = (int)(s1 - s0);
+    } else {
+        const int jt0 = split * a.jt_per_split;
+        int jt1 = jt0 + a.jt_per_split;
+        if (jt1 > a.jtiles) jt1 = a.jtiles;
+        g0 = jt0 * a.Fs;
+        nsteps = (jt1 > jt0) ? (jt1 - jt0) * a.Fs : 0;
+    }
 
     f32x16 acc[MT_W][NT_W][TAPS];
 #pragma unroll
@@ -82,7 +91,8 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
     // mapped memory) and the validity masks are applied when the registers are written to LDS one step later -- a
     // conditional load followed by its mask makes the compiler wait for each load in turn (vmcnt(0) after every one).
     auto load_step = [&](int step) {
-        const int jt = jt0 + step / a.Fs, fs = step - (step / a.Fs) * a.Fs;
+        const int g = g0 + step;
+        const int jt = g / a.Fs, fs = g - jt * a.Fs;
         const int j0 = jt * WG_JT;
 #pragma unroll
         for (int i = 0; i < NS4; ++i) {
@@ -116,7 +126,8 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
         }
     };
     auto store_step = [&](int step) {
-        const int jt = jt0 + step / a.Fs, fs = step - (step / a.Fs) * a.Fs;
+        const int g = g0 + step;
+        const int jt = g / a.Fs, fs = g - jt * a.Fs;
         const int j0 = jt * WG_JT;
 #pragma unroll
         for (int i = 0; i < NS4; ++i) {
@@ -453,7 +464,7 @@ extern "C" long long idv_cconv_wgrad_work_floats(int Cs, int Cl, int B, int Tp) 
         const SkinnyPlan k = skinny_plan(2 * Cs, B * Tp);
         return (long long)k.nsplit * 10 * k.SpPad * k.LpPad;
     }
-    const Plan p = make_plan(2 * Cs, 2 * Cl, B * Tp, CONV_MS, CONV_ML, CONV_JT);
+    const Plan p = make_plan_rounds(2 * Cs, 2 * Cl, B * Tp, CONV_MS, CONV_ML, CONV_JT, 1, 2, 0);      // upper bound: Fs unknown here
     return (long long)p.nsplit * 10 * p.SpPad * p.LpPad;
 }
 
@@ -489,9 +500,10 @@ extern "C" int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const 
                            k.SpPad, k.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
         return idv_launch_status();
     }
-    const Plan p = make_plan(a.Sp, a.Lp, a.J, CONV_MS, CONV_ML, CONV_JT);
+    const Plan p = make_plan_rounds(a.Sp, a.Lp, a.J, CONV_MS, CONV_ML, CONV_JT, 1, 2, a.Fs);
     if ((long long)p.nsplit * 10 * p.SpPad * p.LpPad > work_floats) return IDV_EINVAL;
-    a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles; a.jt_per_split = p.jt_per_split;
+    a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles;
+    a.nsplit_bal = p.nsplit; a.steps_total = (long long)p.jtiles * a.Fs;
     hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 4, 1, CONV_JT, 2>), dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_unpack_conv_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work, p.nsplit,
                        p.SpPad, p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
@@ -504,8 +516,7 @@ const bool WGRAD_GAUSS = [] { const char* e = getenv("IDV_WGRAD_GAUSS"); return 
 struct GaussPlan { Plan p; long long prod_stride, part_floats, s_comb, l_comb; };
 inline GaussPlan gauss_plan(int Cs, int Cl, int Fs, int Fl, int J, int JpS, int JpL) {
     GaussPlan g;
-    g.p = make_plan(Cs, Cl, J, CONV_MS, CONV_ML, CONV_JT);
-    // make_plan aims its workgroup count at ONE contraction; there are three in the launch
+    g.p = make_plan_rounds(Cs, Cl, J, CONV_MS, CONV_ML, CONV_JT, 3, 2, Fs);
     g.prod_stride = (long long)g.p.nsplit * 10 * g.p.SpPad * g.p.LpPad;
     g.part_floats = 3 * g.prod_stride;
     g.s_comb = ((long long)Cs * Fs * JpS + 63) / 64 * 64;
@@ -572,7 +583,8 @@ extern "C" int idv_cconv2d_bwd_weight_gauss(const float* x, int Cx, int ci_off, 
     a.S1 = S_im;  a.L1 = L_im;    // P2 = q v
     a.S2 = s_dif; a.L2 = l_sum;   // P3 = (p - q)(u + v)
     a.nprod = 3; a.tilesL = g.p.tilesL; a.prod_stride = g.prod_stride;
-    a.part = work; a.SpPad = g.p.SpPad; a.LpPad = g.p.LpPad; a.jtiles = g.p.jtiles; a.jt_per_split = g.p.jt_per_split;
+    a.part = work; a.SpPad = g.p.SpPad; a.LpPad = g.p.LpPad; a.jtiles = g.p.jtiles;
+    a.nsplit_bal = g.p.nsplit; a.steps_total = (long long)g.p.jtiles * a.Fs;
     const dim3 grid(g.p.nsplit, g.p.tilesS, 3 * g.p.tilesL);
     hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 4, 1, CONV_JT, 2>), grid, dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_unpack_gauss_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work, g.prod_stride,

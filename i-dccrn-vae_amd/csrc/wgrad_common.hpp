@@ -24,6 +24,10 @@ struct WgradArgs {
     int nprod, tilesL;
     const float *S1, *S2, *L1, *L2;      // products 1 and 2 (product 0: S, L)
     long long prod_stride;
+    // balanced split-K (make_plan_rounds): split i owns the steps [i * steps_total / nsplit_bal, (i + 1) * steps_total / nsplit_bal)
+    // of the flattened (column tile, frequency row) sequence; 0: whole column tiles per split (jt_per_split)
+    int nsplit_bal;
+    long long steps_total;
 };
 
 struct Plan { int tilesS, tilesL, nsplit, jtiles, jt_per_split, SpPad, LpPad; };
@@ -43,6 +47,56 @@ inline Plan make_plan(int Sp, int Lp, int J, int MS, int ML, int JT) {
     if (want > p.jtiles) want = p.jtiles;
     p.jt_per_split = (p.jtiles + want - 1) / want;
     p.nsplit = (p.jtiles + p.jt_per_split - 1) / p.jt_per_split;
+    return p;
+}
+
+inline int device_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            n <= 0) {
+            (void)hipGetLastError();
+            return 256;                       // no device visible (sizing queries in the build container): the MI355X figure
+        }
+        return n;
+    }();
+    return cus;
+}
+
+// Split-K plan aimed at WHOLE rounds of resident workgroups: `tiles` output tiles (S tiles x L tiles x products) x nsplit equal
+// splits = just under rounds x (CUs x occupancy) workgroups, every split the same number of (column tile, frequency row)
+// steps to within one.  The round count (1 .. WGRAD_MAX_ROUNDS) minimises  rounds x (steps per split + ~16 steps of per-workgroup
+// prologue / partial-tile write), a model fitted to tests/tools/wgrad_layers_probe.py at B = 32 (it picks within 0.3 % of
+// the best measured round count on every DCCRN-CL layer; the 1024-workgroup target of make_plan left partial last rounds,
+// e.g. 5.02, that cost up to 25 % on single layers and 6 % over the step).  Fs = 0: the plan with the most splits (work-space bound).
+// IDV_WGRAD_ROUNDS forces the round count (experiments).
+constexpr int WGRAD_MAX_ROUNDS = 4;
+inline Plan make_plan_rounds(int Sp, int Lp, int J, int MS, int ML, int JT, int nprod, int occ, int Fs) {
+    Plan p;
+    p.tilesS = (Sp + MS - 1) / MS;
+    p.tilesL = (Lp + ML - 1) / ML;
+    p.SpPad = p.tilesS * MS;
+    p.LpPad = p.tilesL * ML;
+    p.jtiles = (J + JT - 1) / JT;
+    p.jt_per_split = 0;
+    static const int forced = [] { const char* e = getenv("IDV_WGRAD_ROUNDS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const long long slots = (long long)device_cus() * occ, tiles = (long long)p.tilesS * p.tilesL * nprod;
+    auto splits = [&](int r) {
+        long long ns = slots * r / tiles;
+        if (ns < 1) ns = 1;
+        if (ns > p.jtiles) ns = p.jtiles;
+        return ns;
+    };
+    if (forced) { p.nsplit = (int)splits(forced); return p; }
+    if (Fs <= 0) { p.nsplit = (int)splits(WGRAD_MAX_ROUNDS); return p; }
+    const double steps = (double)p.jtiles * Fs;
+    double best_cost = 0;
+    p.nsplit = 1;
+    for (int r = 1; r <= WGRAD_MAX_ROUNDS; ++r) {
+        const long long ns = splits(r), wgs = tiles * ns, rounds = (wgs + slots - 1) / slots;
+        const double cost = (double)rounds * (steps / (double)ns + 16.0);
+        if (r == 1 || cost < best_cost) { best_cost = cost; p.nsplit = (int)ns; }
+    }
     return p;
 }
 
