@@ -655,6 +655,10 @@ static long long hp_floats(int H, int B, int Jp) {
         const long long m = (idv_lstm_pers_f32_work_bytes(H, B) + 3) / 4;
         if (m > n) n = m;
     }
+    if (idv_lstm_stack2_f32_supported(H, B)) {
+        const long long m = (idv_lstm_stack2_f32_work_bytes(H, B) + 3) / 4;
+        if (m > n) n = m;
+    }
     return (n + 63) / 64 * 64;
 }
 
@@ -667,9 +671,9 @@ extern "C" long long idv_clstm_train_work_floats(int H, int B, int T, int Jp) {
     return 48LL * T * B * H + 4LL * B * H + hp_floats(H, B, Jp) + 4LL * H * Jp;      // + split image of h0 (bf16x3 mode)
 }
 
-extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
-                             const float* wih1, const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp,
-                             float* work, float* out, int flags, const void* wih1_bf16, void* stream) {
+static int clstm_fwd_impl(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
+                          const float* wih1, const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp,
+                          float* work, float* out, int flags, const void* wih1_bf16, const float* wih1_hh, void* stream) {
     if (!x || !wih0 || !bih0 || !whh0 || !wih1 || !bih1 || !whh1 || !work || !out) return IDV_EINVAL;
     if (H <= 0 || (H % 16) || K <= 0 || (K & 1) || B <= 0 || T <= 0 || Tp < T + 1 || Jp < B * Tp) return IDV_EINVAL;
     if ((size_t)3 * H * 16 * sizeof(float) > 160 * 1024) return IDV_EINVAL;
@@ -701,6 +705,19 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
     float* hp = cstate + 4LL * B * H;                  // [4 runs][H][Jp] (per-step path) / exchange buffer (persistent path)
     void* himg = (void*)(hp + hp_floats(H, B, Jp));    // [hi | lo][4 runs][H/8][Jp] x 16 B
     const long long himg_lo = 4LL * (H / 8) * Jp;
+    // exact-fp32 evaluation at H = 128 with W_ih of layer 1 in the recurrence's fragment order: both layers in one
+    // cooperative launch, layer 1 one step behind layer 0, no hoisted layer-1 projection (lstm_stack2_f32.hip)
+    if (wih1_hh && !save && !(flags & 1) && !(flags & 8) && idv_lstm_stack2_f32_supported(H, B) && 16LL * TB * H < 0xfffffe00LL) {
+        if ((rc = idv_lstm_stack2_f32(G, TB * 8 * H, 4LL * H, 8 * H, whh0, wih1_hh, whh1, bih1, h0, h1, H, B, T,
+                                      (void*)(cstate + 4LL * B * H), stream)))
+            return rc;
+        hipLaunchKernelGGL(lstm_combine_kernel, dim3((T + 31) / 32, (H + 31) / 32, B), dim3(256), 0, st, h1, H, B, T, Tp, Jp, out);
+        const long long ntail2 = 2LL * H * B * (Tp - 1 - T);
+        if (ntail2 > 0)
+            hipLaunchKernelGGL(zero_tail_kernel, dim3((unsigned)((ntail2 + 255) / 256 > 4096 ? 4096 : (ntail2 + 255) / 256)), dim3(256), 0,
+                               st, out, 2 * H, B, T, Tp, Jp);
+        return idv_launch_status();
+    }
     RecArgs r0{G, TB * 8 * H, 4LL * H, 8 * H, whh0, h0, H, B, T, save ? G : nullptr, c0, img1 ? himg : nullptr, himg_lo, Tp, Jp};
     if ((rc = launch_rec(r0, cstate, flags, st))) return rc;
     // layer 1 input projection from h0 (row-major), per run
@@ -737,4 +754,19 @@ extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const flo
         hipLaunchKernelGGL(zero_tail_kernel, dim3((unsigned)((ntail + 255) / 256 > 4096 ? 4096 : (ntail + 255) / 256)), dim3(256), 0,
                            st, out, 2 * H, B, T, Tp, Jp);
     return idv_launch_status();
+}
+
+extern "C" int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
+                             const float* wih1, const float* bih1, const float* whh1, int H, int B, int T, int Tp, int Jp,
+                             float* work, float* out, int flags, const void* wih1_bf16, void* stream) {
+    return clstm_fwd_impl(x, K, wih0, bih0, whh0, wih1, bih1, whh1, H, B, T, Tp, Jp, work, out, flags, wih1_bf16, nullptr, stream);
+}
+
+// idv_clstm_fwd with W_ih of layer 1 ALSO in the recurrence's fragment order (idv_pack_lstm_hh on weight_ih_l1; [4H][H] like
+// W_hh): where idv_lstm_stack2_f32_supported(H, B) the exact-fp32 evaluation runs both layers in one cooperative launch;
+// everything else is idv_clstm_fwd (wih1_hh may be NULL).
+extern "C" int idv_clstm_fwd2(const float* x, int K, const float* wih0, const float* bih0, const float* whh0,
+                              const float* wih1, const float* bih1, const float* whh1, const float* wih1_hh, int H, int B, int T,
+                              int Tp, int Jp, float* work, float* out, int flags, const void* wih1_bf16, void* stream) {
+    return clstm_fwd_impl(x, K, wih0, bih0, whh0, wih1, bih1, whh1, H, B, T, Tp, Jp, work, out, flags, wih1_bf16, wih1_hh, stream);
 }

@@ -601,8 +601,9 @@ extern "C" int idv_cconv2d_bwd_bias(const double* stats_dy, int Cout, float* db_
 
 extern "C" long long idv_pw_wgrad_work_floats(int M, int K, int J) {
     if (M <= 0 || K <= 0 || J <= 0) return -1;
-    const Plan p = make_plan(M, K, J, 128, 128, PW_JT);
-    return (long long)p.nsplit * p.SpPad * p.LpPad;
+    const Plan p = make_plan_rounds(M, K, J, 128, 128, PW_JT, 1, 1, 1);
+    const Plan q = make_plan(M, K, J, 128, 128, PW_JT);       // idv_pw_bwd_weight_bf16x3 (same tile, its own split) shares this size
+    return (long long)(p.nsplit > q.nsplit ? p.nsplit : q.nsplit) * p.SpPad * p.LpPad;
 }
 
 extern "C" int idv_pw_bwd_weight(const float* dout, int M, int Jp_d, const float* x, int K, int Jp_x, int J, int shift,
@@ -615,9 +616,10 @@ extern "C" int idv_pw_bwd_weight(const float* dout, int M, int Jp_d, const float
     a.S = dout; a.Sp = M; a.Fs = 1; a.JpS = Jp_d;
     a.L = x;    a.Lp = K; a.Fl = 1; a.JpL = Jp_x;
     a.dt0 = shift; a.J = J;
-    const Plan p = make_plan(M, K, J, 128, 128, PW_JT);
+    const Plan p = make_plan_rounds(M, K, J, 128, 128, PW_JT, 1, 1, 1);
     if ((long long)p.nsplit * p.SpPad * p.LpPad > work_floats) return IDV_EINVAL;
-    a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles; a.jt_per_split = p.jt_per_split;
+    a.part = work; a.SpPad = p.SpPad; a.LpPad = p.LpPad; a.jtiles = p.jtiles;
+    a.nsplit_bal = p.nsplit; a.steps_total = p.jtiles;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((wgrad_kernel<1, 1, 2, 2, 2, 2, PW_JT, 1>), dim3(p.nsplit, p.tilesS, p.tilesL), dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_unpack_plain_kernel, dim3(grid_for((long long)M * K)), dim3(256), 0, st, work, p.nsplit, p.SpPad,

@@ -551,12 +551,20 @@ def pack_lstm(sd_get, H: int, K: int, layer: int, device):
         wih16 = torch.empty(int(L.lib().idv_lstm_ih_bf16_bytes(i(H), i(K))), dtype=torch.uint8, device=device)
         call("idv_pack_lstm_ih_bf16", p(g(f"lstm_re.weight_ih_l{l}")), p(g(f"lstm_im.weight_ih_l{l}")), i(H), i(K), p(wih16),
              stream_ptr())
-    return wih, bih, whh, wih16
+    # layer 1 at H = 128: W_ih ([4H][H] like W_hh) in the recurrence's fragment order too, for the two-layer cooperative
+    # launch of the fp32 evaluation (csrc/lstm_stack2_f32.hip)
+    wih_hh = None
+    if layer == 1 and K == H and H == 128:
+        wih_hh = torch.empty(4 * 4 * H * H, dtype=torch.float32, device=device)
+        call("idv_pack_lstm_hh", p(g(f"lstm_re.weight_ih_l{l}")), p(g(f"lstm_im.weight_ih_l{l}")), i(H), p(wih_hh), stream_ptr())
+    return wih, bih, whh, wih16, wih_hh
 
 
 # bf16x3 mode, H = 384 / 768: one persistent cooperative launch per layer (csrc/lstm_pers.hip) instead of one launch per
 # time step; IDV_LSTM_PERSISTENT=0 keeps the per-step kernels
 LSTM_PERSISTENT = os.environ.get("IDV_LSTM_PERSISTENT", "1") != "0"
+# fp32 evaluation, H = 128: both layers in one cooperative launch (csrc/lstm_stack2_f32.hip); 0 keeps one launch per layer
+LSTM_STACK2 = os.environ.get("IDV_LSTM_STACK2", "1") != "0"
 
 
 def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
@@ -574,9 +582,9 @@ def clstm(x: Planar, packed0, packed1, H: int) -> Planar:
         call("idv_lstm_proj_bf16x3", kimg.ptr(), ll(kimg.lo_slots), i(K), p(packed0[3]), p(packed0[1]), p(work), i(H), i(x.B),
              i(x.T), i(x.Tp), i(x.Jp), stream_ptr())
         flags |= 2
-    call("idv_clstm_fwd", x.ptr(), i(K), p(packed0[0]), p(packed0[1]), p(packed0[2]), p(packed1[0]), p(packed1[1]),
-         p(packed1[2]), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(), i(flags),
-         p(packed1[3] if (flags & 1) else None), stream_ptr())
+    call("idv_clstm_fwd2", x.ptr(), i(K), p(packed0[0]), p(packed0[1]), p(packed0[2]), p(packed1[0]), p(packed1[1]),
+         p(packed1[2]), p(packed1[4] if (LSTM_STACK2 and len(packed1) > 4) else None), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(),
+         i(flags), p(packed1[3] if (flags & 1) else None), stream_ptr())
     return out
 
 

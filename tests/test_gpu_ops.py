@@ -421,7 +421,7 @@ def test_clstm_persistent_matches_per_step(ops, H, B, T):
     assert relerr(got.cpu(), ref.cpu()) < 2e-4
 
 
-@pytest.mark.parametrize("B,T", [(5, 40), (40, 33), (64, 641)])
+@pytest.mark.parametrize("B,T", [(5, 40), (40, 33), (64, 641), (100, 7)])
 def test_clstm_coop_f32_matches_one_cu(ops, B, T):
     """The exact-fp32 H = 128 recurrence spread over four CUs per sequence tile (lstm_coop_f32.hip: gate columns split over
     workgroups, h exchanged through global memory) against the one-CU register-resident kernel on the same inputs: same
@@ -437,7 +437,7 @@ def test_clstm_coop_f32_matches_one_cu(ops, B, T):
         sd[n] = O.synth_tensor(n, shape, 93) * (2.0 if "weight" in n else 1.0)
     xp = ops.Planar.from_tensor5(x.permute(1, 2, 0, 3).unsqueeze(2).cuda())
     get = lambda n: sd[n].cuda()
-    keep = (ops.PRECISION, ops.LSTM_PERSISTENT)
+    keep = (ops.PRECISION, ops.LSTM_PERSISTENT, ops.LSTM_STACK2)
     try:
         ops.set_precision("fp32")
         p0, p1 = ops.pack_lstm(get, H, I, 0, "cuda"), ops.pack_lstm(get, H, H, 1, "cuda")
@@ -445,15 +445,24 @@ def test_clstm_coop_f32_matches_one_cu(ops, B, T):
         ref = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
         ops.LSTM_PERSISTENT = True
         assert amd_lib().idv_lstm_coop_f32_supported(H, B)
+        ops.LSTM_STACK2 = False                                      # one cooperative launch per layer
         got = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
-        got2 = ops.clstm(xp, p0, p1, H).channel_slice(0, H)
+        got2 = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
+        # both layers in ONE cooperative launch, layer 1 a step behind layer 0 and its input projection inside the recurrence
+        # (lstm_stack2_f32.hip): W_ih h0[t] is summed in another order than the hoisted GEMM does -> 1e-6, bit-repeatable
+        ops.LSTM_STACK2 = True
+        assert amd_lib().idv_lstm_stack2_f32_supported(H, B) and p1[4] is not None
+        st = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
+        st2 = ops.clstm(xp, p0, p1, H).channel_slice(0, H).clone()
         torch.cuda.synchronize()
     finally:
         ops.set_precision(keep[0])
         ops.LSTM_PERSISTENT = keep[1]
-    assert torch.isfinite(got).all()
-    assert torch.equal(got, got2)
+        ops.LSTM_STACK2 = keep[2]
+    assert torch.isfinite(got).all() and torch.isfinite(st).all()
+    assert torch.equal(got, got2) and torch.equal(st, st2)
     assert relerr(got.cpu(), ref.cpu()) < 1e-6
+    assert relerr(st.cpu(), ref.cpu()) < 1e-6
 
 
 @pytest.mark.parametrize("H,precision", [(128, "fp32"), (384, "bf16x3"), (384, "fp32")])
