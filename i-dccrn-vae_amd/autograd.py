@@ -363,8 +363,9 @@ class LstmFn(torch.autograd.Function):
                      i(x.Tp), i(x.Jp), stream_ptr())
                 flags |= 2
             wih1_16 = p1[3]
-        call("idv_clstm_fwd", x.ptr(), i(K), p(p0[0]), p(p0[1]), p(p0[2]), p(p1[0]), p(p1[1]), p(p1[2]), i(H), i(x.B), i(x.T),
-             i(x.Tp), i(x.Jp), p(work), out.ptr(), i(flags), p(wih1_16), stream_ptr())
+        call("idv_clstm_fwd2", x.ptr(), i(K), p(p0[0]), p(p0[1]), p(p0[2]), p(p1[0]), p(p1[1]), p(p1[2]),
+             p(p1[4] if (ops.LSTM_STACK2 and len(p1) > 4) else None), i(H), i(x.B), i(x.T), i(x.Tp), i(x.Jp), p(work), out.ptr(),
+             i(flags), p(wih1_16), stream_ptr())
         ctx.save_for_backward(xbuf, work, *params)
         ctx.mod, ctx.geom, ctx.ogeom = mod, geom, _geom(out)
         return out.buf

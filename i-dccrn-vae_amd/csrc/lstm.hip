@@ -705,11 +705,12 @@ static int clstm_fwd_impl(const float* x, int K, const float* wih0, const float*
     float* hp = cstate + 4LL * B * H;                  // [4 runs][H][Jp] (per-step path) / exchange buffer (persistent path)
     void* himg = (void*)(hp + hp_floats(H, B, Jp));    // [hi | lo][4 runs][H/8][Jp] x 16 B
     const long long himg_lo = 4LL * (H / 8) * Jp;
-    // exact-fp32 evaluation at H = 128 with W_ih of layer 1 in the recurrence's fragment order: both layers in one
-    // cooperative launch, layer 1 one step behind layer 0, no hoisted layer-1 projection (lstm_stack2_f32.hip)
-    if (wih1_hh && !save && !(flags & 1) && !(flags & 8) && idv_lstm_stack2_f32_supported(H, B) && 16LL * TB * H < 0xfffffe00LL) {
+    // exact fp32 at H = 128 with W_ih of layer 1 in the recurrence's fragment order: both layers in one cooperative launch,
+    // layer 1 one step behind layer 0, no hoisted layer-1 projection (lstm_stack2_f32.hip); the training forward keeps the
+    // same buffers as the per-layer path (activated gates over G / in G1, cell states)
+    if (wih1_hh && !(flags & 1) && !(flags & 8) && idv_lstm_stack2_f32_supported(H, B) && 16LL * TB * H < 0xfffffe00LL) {
         if ((rc = idv_lstm_stack2_f32(G, TB * 8 * H, 4LL * H, 8 * H, whh0, wih1_hh, whh1, bih1, h0, h1, H, B, T,
-                                      (void*)(cstate + 4LL * B * H), stream)))
+                                      (void*)(cstate + 4LL * B * H), save ? G1 : nullptr, c0, c1, stream)))
             return rc;
         hipLaunchKernelGGL(lstm_combine_kernel, dim3((T + 31) / 32, (H + 31) / 32, B), dim3(256), 0, st, h1, H, B, T, Tp, Jp, out);
         const long long ntail2 = 2LL * H * B * (Tp - 1 - T);

@@ -1,5 +1,6 @@
 // Both layers of the DCCRN-CL bottleneck LSTM (H = 128, exact fp32; reference ComplexLSTM.forward, model/complex_progress.py:50-74:
-// two nn.LSTM(num_layers = 2), each applied to the real and to the imaginary input) in ONE cooperative launch, evaluation only.
+// two nn.LSTM(num_layers = 2), each applied to the real and to the imaginary input) in ONE cooperative launch (evaluation, and
+// the training forward: the activated gates and cell states idv_lstm_bptt reads are kept).
 //
 // lstm_coop_f32.hip runs a layer as 641 latency-bound steps of 3.3 us on 64 CUs and needs layer 0 finished before layer 1's
 // input projection (a separate GEMM) and recurrence start: 2 x 2.1 ms + 0.6 ms per forward, 5 % of the fp32 headline step
@@ -35,6 +36,9 @@ struct Args {
     float* h0;                // [4 runs][T*B][H]: layer-0 output, read by the layer-1 workgroups
     unsigned h0_bytes;
     float* hout;              // [4 runs][T*B][H]: layer-1 output
+    float* gsave1;            // training forward: activated gates of layer 1 [run][T*B][4H] (layer 0: over g, in place) ...
+    float* csave0;            // ... and the cell states [4 runs][T*B][H] of both layers; all three NULL in evaluation
+    float* csave1;
     float* hx;                // exchange [2 layers][2 parity][4 runs][Bpad][H] fp32
     unsigned hx_bytes;
     unsigned* sync;           // [abort flag: 256 B][layer][group = run * tiles + tile][replica][256 B]
@@ -120,6 +124,10 @@ __global__ __launch_bounds__(256, 1) void lstm_stack2_f32_kernel(const Args a) {
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) gb[ub][gg] = layer ? a.bias1[(size_t)s * 4 * H + (2 * sl + ub) * 64 + 16 * gg + col] : 0.f;
     const float* g = a.g + z * a.g_run_z + s * a.g_run_s;
+    // training forward: where this workgroup keeps its activated gates (row pitch gld) and cell states
+    float* gsv = !a.csave0 ? nullptr : (layer ? a.gsave1 + (size_t)run * TB * 4 * H : const_cast<float*>(g));
+    const int gld = layer ? 4 * H : a.ldg;
+    float* csv = layer ? a.csave1 : a.csave0;
 
     bool aborted = false;
     if (tid == 0) abort_sh = 0;
@@ -216,6 +224,11 @@ __global__ __launch_bounds__(256, 1) void lstm_stack2_f32_kernel(const Args a) {
             const float cn = fg * creg[ub] + ig * gv;
             creg[ub] = cn;
             stage[myrow][ub * 16 + col] = og * tanhf_(cn);
+            if (gsv && rowok) {
+                float* gp = gsv + ((size_t)t * a.B + brow) * gld + (2 * sl + ub) * 64 + col;
+                gp[0] = ig; gp[16] = fg; gp[32] = gv; gp[48] = og;
+                csv[(size_t)run * TBH + ((size_t)t * a.B + brow) * H + sl * UPW + ub * 16 + col] = cn;
+            }
         }
         __syncthreads();
         if (tid < 128) {
@@ -266,15 +279,18 @@ extern "C" long long idv_lstm_stack2_f32_work_bytes(int H, int B) {
     return idv_stack2::SYNC_BYTES + 2LL * 2 * 4 * Bpad * H * 4;
 }
 
-// Both layers of the H = 128 complex LSTM in one cooperative launch (evaluation).  g: layer-0 gate pre-activations as for
+// Both layers of the H = 128 complex LSTM in one cooperative launch.  g: layer-0 gate pre-activations as for
 // idv_lstm_rec_coop_f32; whh0 / wih1_hh / whh1: idv_pack_lstm_hh fragments (W_ih of layer 1 is [4H][H] too); bias1: [2][4H] in
 // gate-column order (idv_pack_lstm_ih of layer 1); h0, hout: [4 runs][T*B][H]; work: idv_lstm_stack2_f32_work_bytes bytes.
+// Training forward: gsave1 ([run][T*B][4H]), csave0, csave1 ([4 runs][T*B][H]) all non-NULL -- the activated gates of layer 0
+// replace its pre-activations in g, those of layer 1 go to gsave1 (the layouts idv_lstm_bptt reads); evaluation: all NULL.
 extern "C" int idv_lstm_stack2_f32(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh0, const float* wih1_hh,
                                    const float* whh1, const float* bias1, float* h0, float* hout, int H, int B, int T, void* work,
-                                   void* stream) {
+                                   float* gsave1, float* csave0, float* csave1, void* stream) {
     using namespace idv_stack2;
     if (!g || !whh0 || !wih1_hh || !whh1 || !bias1 || !h0 || !hout || !work || T <= 0 || !idv_lstm_stack2_f32_supported(H, B))
         return IDV_EINVAL;
+    if ((gsave1 != nullptr) != (csave0 != nullptr) || (csave0 != nullptr) != (csave1 != nullptr)) return IDV_EINVAL;
     if ((reinterpret_cast<uintptr_t>(work) & 15) || (reinterpret_cast<uintptr_t>(h0) & 15) || (reinterpret_cast<uintptr_t>(hout) & 15))
         return IDV_EINVAL;
     const long long h0_bytes = 4LL * T * B * H * 4;
@@ -287,6 +303,7 @@ extern "C" int idv_lstm_stack2_f32(const float* g, long long g_run_z, long long 
     a.g = g; a.g_run_z = g_run_z; a.g_run_s = g_run_s; a.ldg = ldg;
     a.whh0 = whh0; a.wih1 = wih1_hh; a.whh1 = whh1; a.bias1 = bias1;
     a.h0 = h0; a.h0_bytes = (unsigned)h0_bytes; a.hout = hout;
+    a.gsave1 = gsave1; a.csave0 = csave0; a.csave1 = csave1;
     a.sync = (unsigned*)work;
     a.hx = (float*)((char*)work + SYNC_BYTES);
     a.hx_bytes = (unsigned)(2LL * 2 * 4 * Bpad * H * 4);

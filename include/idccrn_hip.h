@@ -298,17 +298,20 @@ int idv_clstm_fwd(const float* x, int K, const float* wih0, const float* bih0, c
                   int flags, const void* wih1_bf16, void* stream);
 
 /* Both layers of the H = 128 complex LSTM (reference ComplexLSTM.forward, model/complex_progress.py:50-74: nn.LSTM(num_layers = 2))
- * in ONE cooperative launch, exact fp32, evaluation (lstm_stack2_f32.hip): layer 1 runs one step behind layer 0 on its own four
+ * in ONE cooperative launch, exact fp32 (lstm_stack2_f32.hip): layer 1 runs one step behind layer 0 on its own four
  * CUs per (run, 16-sequence tile) and computes W_ih h0[t+1] in the hand-off latency of its own step t, so the hoisted layer-1
  * projection GEMM and the second recurrence launch disappear.  wih1_hh: idv_pack_lstm_hh applied to weight_ih_l1 (re, im) --
  * [4H][H] like W_hh; bias1: bih of idv_pack_lstm_ih for layer 1 ([2 sets][4H], gate-column order); h0, hout: [4 runs][T*B][H];
- * work: idv_lstm_stack2_f32_work_bytes bytes, 16-byte aligned.  Supported: H == 128 and 32 * ceil(B/16) <=
- * idv_coop_max_workgroups() (IDV_LSTM_STACK2=0 turns it off).  idv_clstm_fwd2 = idv_clstm_fwd + wih1_hh (may be NULL): takes this
- * path in fp32 evaluation where supported, idv_clstm_fwd's otherwise. */
+ * work: idv_lstm_stack2_f32_work_bytes bytes, 16-byte aligned; gsave1 ([run][T*B][4H]) / csave0 / csave1 ([4 runs][T*B][H]):
+ * training forward (all three; layer 0's activated gates replace g in place -- the buffers idv_lstm_bptt reads) or all NULL.
+ * Supported: H == 128 and 32 * ceil(B/16) <= idv_coop_max_workgroups() (IDV_LSTM_STACK2=0 turns it off).
+ * idv_clstm_fwd2 = idv_clstm_fwd + wih1_hh (may be NULL): takes this path in fp32 mode (evaluation and flags bit 2) where
+ * supported, idv_clstm_fwd's otherwise. */
 int idv_lstm_stack2_f32_supported(int H, int B);
 long long idv_lstm_stack2_f32_work_bytes(int H, int B);
 int idv_lstm_stack2_f32(const float* g, long long g_run_z, long long g_run_s, int ldg, const float* whh0, const float* wih1_hh,
-                        const float* whh1, const float* bias1, float* h0, float* hout, int H, int B, int T, void* work, void* stream);
+                        const float* whh1, const float* bias1, float* h0, float* hout, int H, int B, int T, void* work,
+                        float* gsave1, float* csave0, float* csave1, void* stream);
 int idv_clstm_fwd2(const float* x, int K, const float* wih0, const float* bih0, const float* whh0, const float* wih1,
                    const float* bih1, const float* whh1, const float* wih1_hh, int H, int B, int T, int Tp, int Jp, float* work,
                    float* out, int flags, const void* wih1_bf16, void* stream);
