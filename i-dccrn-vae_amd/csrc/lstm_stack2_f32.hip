@@ -53,11 +53,19 @@ constexpr unsigned long long SPIN_LIMIT_TICKS = 40000000ull;     // 0.4 s of the
 constexpr int MAX_GROUPS = 64, MAX_REP = 8;
 constexpr int SYNC_BYTES = 256 + 2 * MAX_GROUPS * MAX_REP * 256;
 
-// thread 0 of the workgroup: wait until *counter >= want (bounded); 1 in *abort_sh when the launch is being abandoned
-__device__ __forceinline__ void wait_for(unsigned* counter, unsigned want, unsigned* abortf, int* abort_sh) {
+// thread 0 of the workgroup: wait until *counter >= want (bounded); 1 in *abort_sh when the launch is being abandoned;
+// *seen (if given) <- the last value read
+// (other, other_seen): a second counter read ONCE if the first check fails, i.e. only when there is time to spare
+__device__ __forceinline__ void wait_for(unsigned* counter, unsigned want, unsigned* abortf, int* abort_sh, unsigned* seen = nullptr,
+                                         unsigned* other = nullptr, unsigned* other_seen = nullptr) {
     const unsigned long long t0 = wall_clock64();
     unsigned long long spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    unsigned v;
+    while ((v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want) {
+        if (other) {
+            *other_seen = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            other = nullptr;
+        }
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023) == 0) {
             if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { *abort_sh = 1; break; }
@@ -68,11 +76,13 @@ __device__ __forceinline__ void wait_for(unsigned* counter, unsigned want, unsig
             }
         }
     }
+    if (seen) *seen = v;
 }
 
 __global__ __launch_bounds__(256, 1) void lstm_stack2_f32_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) float red[];                // [4 waves][8 tiles][4 r][64 lanes]
     __shared__ int abort_sh;
+    __shared__ unsigned seen0_sh;                                              // layer 1: layer-0 arrivals last observed
     __shared__ __attribute__((aligned(16))) float stage[16][UPW];              // h_t of this workgroup: [row][unit]
     const __amdgpu_buffer_rsrc_t hxr = __builtin_amdgcn_make_buffer_rsrc((void*)a.hx, 0, a.hx_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t h0r = __builtin_amdgcn_make_buffer_rsrc((void*)a.h0, 0, a.h0_bytes, 0x00020000);
@@ -130,41 +140,29 @@ __global__ __launch_bounds__(256, 1) void lstm_stack2_f32_kernel(const Args a) {
     float* csv = layer ? a.csave1 : a.csave0;
 
     bool aborted = false;
-    if (tid == 0) abort_sh = 0;
+    if (tid == 0) { abort_sh = 0; seen0_sh = 0; }
     if (a.fault && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) return;      // injected failure (tests only)
     __syncthreads();
 
-    f32x4 acc_in[8];                  // layer 1: W_ih h0[t], computed one step ahead
-#pragma unroll
-    for (int t8 = 0; t8 < 8; ++t8)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc_in[t8][r] = 0.f;
-    // layer 1: acc_in <- W_ih h0[tt] once layer 0 has published step tt
-    auto input_part = [&](int tt) -> bool {
-        if (tid == 0) wait_for(cnt0 + (size_t)rep * 64, (unsigned)(tt + 1) * (unsigned)NSL, abortf, &abort_sh);
+    // layer 1: the rows of h0[t] for the CURRENT step sit in registers (cur0, cur1) when the step starts; W_ih h0[t] is
+    // contracted while the loads of h1[t-1] are in flight, so it costs no time of its own.  Layer 0 runs ahead (its step is
+    // shorter): its arrival count is polled only when the cached one does not cover the step, and the rows of h0[t+1] are
+    // requested EARLY -- before this step's own stores and arrive.
+    auto input_known = [&](int tt) -> bool { return seen0_sh >= (unsigned)(tt + 1) * (unsigned)NSL; };       // uniform
+    auto input_load = [&](int tt, f32x4& a0, f32x4& a1) {
+        const unsigned off = (unsigned)((((size_t)run * TB + (size_t)tt * a.B + lrow) * H + 32 * wave + 8 * rq) * 4u);
+        a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h0r, off, 0, 16));
+        a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h0r, off + 16u, 0, 16));
+    };
+    auto input_late = [&](int tt, f32x4& a0, f32x4& a1) -> bool {            // poll layer 0, then load
+        if (tid == 0) wait_for(cnt0 + (size_t)rep * 64, (unsigned)(tt + 1) * (unsigned)NSL, abortf, &abort_sh, &seen0_sh);
         __syncthreads();
         if (abort_sh) return false;
-        const unsigned off = (unsigned)((((size_t)run * TB + (size_t)tt * a.B + lrow) * H + 32 * wave + 8 * rq) * 4u);
-        const f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h0r, off, 0, 16));
-        const f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h0r, off + 16u, 0, 16));
-        float av[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            av[j] = a0[j];
-            av[4 + j] = a1[j];
-        }
-#pragma unroll
-        for (int t8 = 0; t8 < 8; ++t8)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc_in[t8][r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int t8 = 0; t8 < 8; ++t8)
-                acc_in[t8] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], ireg[t8][j], acc_in[t8], 0, 0, 0);
+        input_load(tt, a0, a1);
         return true;
     };
-    if (layer && !input_part(0)) aborted = true;
+    f32x4 cur0 = {0.f, 0.f, 0.f, 0.f}, cur1 = {0.f, 0.f, 0.f, 0.f};
+    if (layer && !input_late(0, cur0, cur1)) aborted = true;
 
     for (int t = 0; t < a.T && !aborted; ++t) {
         float gpre[2][4];
@@ -182,15 +180,34 @@ __global__ __launch_bounds__(256, 1) void lstm_stack2_f32_kernel(const Args a) {
         }
         f32x4 acc[8];
 #pragma unroll
-        for (int t8 = 0; t8 < 8; ++t8) acc[t8] = acc_in[t8];
+        for (int t8 = 0; t8 < 8; ++t8)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t8][r] = 0.f;
+        auto input_mfma = [&]() {                 // layer 1: acc += W_ih h0[t]
+            float av[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                av[j] = cur0[j];
+                av[4 + j] = cur1[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int t8 = 0; t8 < 8; ++t8)
+                    acc[t8] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], ireg[t8][j], acc[t8], 0, 0, 0);
+        };
+        if (layer && t == 0) input_mfma();
         if (t > 0) {
-            if (tid == 0) wait_for(mine + (size_t)rep * 64, (unsigned)t * (unsigned)NSL, abortf, &abort_sh);
+            if (tid == 0)       // (layer 1: the view of layer 0's progress is refreshed while waiting for the siblings, if it waits)
+                wait_for(mine + (size_t)rep * 64, (unsigned)t * (unsigned)NSL, abortf, &abort_sh, nullptr,
+                         layer ? cnt0 + (size_t)rep * 64 : nullptr, &seen0_sh);
             __syncthreads();                 // the polling wave joins after its match; every load below is sc1
             if (abort_sh) { aborted = true; break; }
             const unsigned par_r = hx_layer + (unsigned)((t - 1) & 1) * hx_par;
             const unsigned off = (((unsigned)run * a.Bpad + b0 + col) * (unsigned)H + 32 * wave + 8 * rq) * 4u;
             const f32x4 a0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hxr, off, par_r, 16));
             const f32x4 a1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hxr, off + 16u, par_r, 16));
+            if (layer) input_mfma();         // under the latency of the two loads above
             float av[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -203,6 +220,10 @@ __global__ __launch_bounds__(256, 1) void lstm_stack2_f32_kernel(const Args a) {
                 for (int t8 = 0; t8 < 8; ++t8)
                     acc[t8] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], breg[t8][j], acc[t8], 0, 0, 0);
         }
+        // layer 1: the next step's input rows, if layer 0 is known to have published them (it usually is)
+        const bool early = layer && t + 1 < a.T && input_known(t + 1);
+        f32x4 nx0 = {0.f, 0.f, 0.f, 0.f}, nx1 = {0.f, 0.f, 0.f, 0.f};
+        if (early) input_load(t + 1, nx0, nx1);
         // ---- reduce the 4 K-partials through LDS: [wave][tile][r][lane], conflict-free dword writes and reads
 #pragma unroll
         for (int t8 = 0; t8 < 8; ++t8)
@@ -248,8 +269,11 @@ __global__ __launch_bounds__(256, 1) void lstm_stack2_f32_kernel(const Args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid < a.nrep) __hip_atomic_fetch_add(mine + (size_t)tid * 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // layer 1: next step's input part while the siblings' h1[t] is in flight
-        if (layer && t + 1 < a.T && !input_part(t + 1)) aborted = true;
+        // layer 1: the next step's input rows, the late way, if they were not requested above
+        if (layer && t + 1 < a.T) {
+            if (!early && !input_late(t + 1, nx0, nx1)) aborted = true;
+            cur0 = nx0; cur1 = nx1;
+        }
     }
     if (aborted) {
         if (tid == 0) idv_coop_raise(a.status);
