@@ -469,19 +469,37 @@ int gauss_config(int transposed, int Cout, int rows) {
     return 300000 + (wide ? 2200 : 1400) + fo * 10 + jc;
 }
 
+// Short-K transposed-conv layers (few input channels: a workgroup's prologue and epilogue weigh against a short main loop) run
+// TWO workgroups per CU with one column tile per wave (6 accumulator tiles, < 256 registers), so that one's prologue / epilogue
+// overlaps the other's MFMAs: dec4 (128 input channels) 6.78 -> 6.17 ms at B = 64; the 512-channel layers lose that way
+// (659 -> 653 utt/s, IDV_GAUSS_TCFG=2).  IDV_GAUSS_OCC2_MAXC moves the boundary (experiments).
+inline int occ2_max_cin() {
+    static const int v = [] { const char* e = getenv("IDV_GAUSS_OCC2_MAXC"); return e ? atoi(e) : 128; }();
+    return v;
+}
+
 template <bool STATS>
 int launch_cfg(const GaussArgs& a, int transposed, hipStream_t st) {
     const int rows = transposed ? a.Fin : a.Fout;
+    // experiment (IDV_GAUSS_CCFG=N): conv layers with <= N input channels on two workgroups per CU (one output row x two column
+    // tiles per wave) like the short-K transposed conv
+    static const int ccfg = [] { const char* e = getenv("IDV_GAUSS_CCFG"); return e ? atoi(e) : 0; }();
+    if (!transposed && ccfg > 0 && a.C0 + a.C1 <= ccfg) {
+        if (a.Cout > 32) return launch_gauss<IDV_CONV, 2, 2, 1, 2, CIK5, STATS, 2>(a, st);
+        return launch_gauss<IDV_CONV, 1, 4, 1, 2, CIK5, STATS, 2>(a, st);
+    }
     switch (gauss_config(transposed, a.Cout, rows)) {
         case 312212: {
             // experiments (IDV_GAUSS_TCFG): 1 = one co tile x four column groups per workgroup, 2 = two waves per SIMD with
             // half the column tiles each
             static const int tcfg = [] { const char* e = getenv("IDV_GAUSS_TCFG"); return e ? atoi(e) : 0; }();
             if (tcfg == 1 && !STATS) return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
-            if (tcfg == 2 && !STATS) return launch_gauss<IDV_TCONV, 2, 2, 1, 1, CIK, STATS, 2>(a, st);
+            if ((tcfg == 2 && !STATS) || a.C0 + a.C1 <= occ2_max_cin()) return launch_gauss<IDV_TCONV, 2, 2, 1, 1, CIK, STATS, 2>(a, st);
             return launch_gauss<IDV_TCONV, 2, 2, 1, 2, CIK, STATS>(a, st);
         }
-        case 311412: return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
+        case 311412:
+            if (a.C0 + a.C1 <= occ2_max_cin()) return launch_gauss<IDV_TCONV, 1, 4, 1, 1, CIK, STATS, 2>(a, st);
+            return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
         case 302251: return launch_gauss<IDV_CONV, 2, 2, 5, 1, CIK5, STATS>(a, st);
         case 302231: return launch_gauss<IDV_CONV, 2, 2, 3, 1, CIK, STATS>(a, st);
         case 302214: return launch_gauss<IDV_CONV, 2, 2, 1, 4, CIK5, STATS>(a, st);

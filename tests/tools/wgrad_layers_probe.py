@@ -13,8 +13,8 @@ L = amd._lib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 T = 641
-ENC = [(1, 32), (32, 64), (64, 128), (128, 256), (256, 256), (256, 256)]
-DEC = [(512, 256), (512, 256), (512, 128), (256, 64), (128, 32), (64, 1)]
+ENC = [(1, 32), (32, 64), (64, 128), (128, 128), (128, 256), (256, 256)]          # model/causal_netconfig.py
+DEC = [(512, 256), (512, 128), (256, 128), (256, 64), (128, 32), (64, 1)]         # input = torch.cat(previous, skip)
 FE = [257, 129, 65, 33, 17, 9, 5]
 dev = "cuda"
 rows = []
