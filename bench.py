@@ -333,13 +333,14 @@ def kernel_name(cfg_id):
         return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
     if cfg_id == 1000001:
         return "void (anonymous namespace)::ctconv_c1_f32_kernel<false>(CgemmArgs, int)"
-    if 300000 <= cfg_id < 400000:       # idv_cconv_gauss_config digits 3 MODE WM WN FO_T JC_W
+    if 3000000 <= cfg_id < 4000000:       # idv_cconv_gauss_config digits 3 MODE WM WN FO_T JC_W OCC
         d = str(cfg_id)
+        occ = int(d[6])
         cik = 2 if (d[1] == "0" and d[4] in "15") else 4                  # cgemm_gauss.hip launch_cfg: CIK5 for the 5- and 1-row conv tiles
         jt = 32 * int(d[5]) * int(d[3])
         fr = 2 * int(d[4]) + 3 if d[1] == "0" else int(d[4]) + 2
-        nbuf = 3 if 3 * cik * 3 * fr * (jt + 8) * 4 <= 156 * 1024 else 2
-        return (f"void (anonymous namespace)::cgemm_gauss_kernel<{d[1]}, {d[2]}, {d[3]}, {d[4]}, {d[5]}, {cik}, false, true, {nbuf}, 1>"
+        nbuf = 3 if 3 * cik * 3 * fr * (jt + 8) * 4 * occ <= 156 * 1024 else 2
+        return (f"void (anonymous namespace)::cgemm_gauss_kernel<{d[1]}, {d[2]}, {d[3]}, {d[4]}, {d[5]}, {cik}, false, true, {nbuf}, {occ}>"
                 "((anonymous namespace)::GaussArgs)")
     if cfg_id > 0:
         d = str(cfg_id)
@@ -398,7 +399,7 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
         "per_kernel": {kernel_name(k): {"tflops": round(2 * v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3)}
                        for k, v in sorted(groups.items())},
     }
-    if 300000 <= dom < 400000 or dom == -95:
+    if 3000000 <= dom < 4000000 or dom == -95:
         # three real products per complex product (Gauss, cgemm_gauss.hip): `achieved` counts the reference's 4 real convolutions
         r["executed"] = round(0.75 * ach, 3)
         r["frac_executed"] = round(0.75 * ach / peak, 4)

@@ -87,9 +87,10 @@ extern "C" int idv_cconv_config(int transposed, int cin_used, int Cout, int Fin)
 
 extern "C" int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div,
                                const float* wfrag, const float* bias, const float* prelu_slope, float* out,
-                               double* stats, int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp,
-                               int t_valid_out, void* stream) {
+                               double* stats, double* stats_work, int stats_rep, int transposed, int tshift, int Cout, int Fin,
+                               int B, int Tp, int Jp, int t_valid_out, void* stream) {
     if (!x0 || !wfrag || !bias || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    if (stats && stats_work && (stats_rep < 2 || (stats_rep & (stats_rep - 1)))) return IDV_EINVAL;
     if (C1 > 0 && (!x1 || x1_div < 1)) return IDV_EINVAL;
     if (tshift != 0 && tshift != -1) return IDV_EINVAL;
     CgemmArgs a{};
@@ -105,7 +106,11 @@ extern "C" int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1,
     const int mode = transposed ? IDV_TCONV : IDV_CONV;
     // one output channel (last decoder block): 2 of the 32 MFMA rows would work; memory-shaped vector-ALU kernel instead
     if (transposed && Cout == 1 && USE_C1_F32) return idv_launch_ctconv_c1_f32(a, st);
-    return stats ? launch_conv<true>(a, mode, st) : launch_conv<false>(a, mode, st);
+    if (!stats) return launch_conv<false>(a, mode, st);
+    if (!stats_work) return launch_conv<true>(a, mode, st);
+    a.stats = stats_work; a.stats_rep = stats_rep;
+    const int rc = launch_conv<true>(a, mode, st);
+    return rc ? rc : idv_launch_stats_collapse(stats_work, stats_rep, Cout * 5, stats, st);
 }
 
 // idv_cconv2d_fwd (eval mode, x1_div == 1) that can also / instead write its result as a split-bf16 image

@@ -44,6 +44,7 @@ struct CgemmArgs {
     int tshift;           // -1: taps (x[t-1], x[t])   0: taps (x[t], x[t+1])
     int t_valid;          // outputs at tp in [1, t_valid] are kept, everything else is zero
     double* stats;        // train mode: [Cout][5] sums (r, i, rr, ii, ri) or nullptr
+    int stats_rep;        // > 1: stats holds that many replicas [rep][Cout][5] (power of two), one chosen per workgroup
     int ldo;              // SWAP: row stride of out; rows are ordered (tp-1)*B + b
     int nB;               // SWAP: utterances (B)
     int jtiles, ftiles, mblocks;   // grid decomposition (filled by the launcher)
@@ -444,7 +445,9 @@ __global__ __launch_bounds__(WM* WN * 64, IDV_WAVES_PER_SIMD) void cgemm_kernel(
                         float t = st[q][s];
 #pragma unroll
                         for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-                        if (l31 == 0 && m < a.M) atomicAdd(&a.stats[(size_t)(m >> 1) * 5 + s], (double)t);
+                        if (l31 == 0 && m < a.M)
+                            atomicAdd(&a.stats[((size_t)(a.stats_rep > 1 ? (blockIdx.x & (a.stats_rep - 1)) : 0) * a.Cout + (m >> 1)) * 5 + s],
+                                      (double)t);
                     }
                 }
             }

@@ -41,6 +41,7 @@ struct GaussArgs {
     int Cout, cotiles;
     int tshift, t_valid;
     double* stats;        // train mode: [Cout][5] sums (r, i, rr, ii, ri) of conv + bias, or nullptr
+    int stats_rep;        // > 1: stats holds that many replicas [rep][Cout][5] (power of two), one chosen per workgroup
     const float* add;     // optional addend, planar [2][Cout][Fout][add_Jp]: added to the contraction before bias / BN / PReLU;
     int add_div, add_Jp;  //   column j of the output reads the addend's utterance b / add_div (a conv of the skip connection
                           //   computed once per utterance and shared by its num_samples latent draws)
@@ -368,7 +369,8 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void cgemm_gauss_kernel(const Gau
                 float t = st[s];
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-                if (l31 == 0 && cok) atomicAdd(&a.stats[(size_t)co * 5 + s], (double)t);
+                if (l31 == 0 && cok)
+                    atomicAdd(&a.stats[((size_t)(a.stats_rep > 1 ? (blockIdx.x & (a.stats_rep - 1)) : 0) * a.Cout + co) * 5 + s], (double)t);
             }
         }
     }
@@ -458,54 +460,61 @@ constexpr int CIK = 4;        // complex input channels per K chunk (wfrag / sup
 constexpr int CIK5 = 2;       // the 5-row conv tile (15 accumulator tiles = 240 registers) and the 1-row x 4-column-tile conv
                               // (13 / 5 patch rows of 72 / 264 .. 520 columns per channel) stage 2 channels per chunk
 
-// configuration id: 3 MODE WM WN FO_T JC_W as decimal digits (leading 3 = the three-product kernel)
-int gauss_config(int transposed, int Cout, int rows) {
+// Two workgroups per CU (6 accumulator tiles per wave, < 256 registers, accumulators in VGPRs) so that one workgroup's prologue
+// (first patch, weight ring) and epilogue overlap the other's MFMAs; per layer, tests/tools/gauss_layers_probe.py, B = 64:
+//   * conv: one output row x two column tiles per wave beats the 12 / 9 / 15-tile one-workgroup forms on EVERY encoder layer
+//     (enc1 3.44 -> 3.24 ms, enc2 6.32 -> 5.78, enc3 6.13 -> 5.84, enc4 6.40 -> 6.23, enc5 7.03 -> 6.94): no frequency-tile
+//     waste, and the short-K layers (32 .. 128 input channels) gain most.  IDV_GAUSS_CCFG=0 restores the old forms,
+//     IDV_GAUSS_CCFG=N limits the new one to <= N input channels;
+//   * transposed conv: one column tile per wave wins at <= 128 input channels (dec4 6.78 -> 6.13 ms) and loses at 256 / 512
+//     (dec3 11.75 -> 11.89 ms; all wide layers 659 -> 653 utt/s), where the 12-tile form amortises its patch reads over two
+//     column tiles.  IDV_GAUSS_OCC2_MAXC moves the boundary.
+inline int occ2_max_cin() {
+    static const int v = [] { const char* e = getenv("IDV_GAUSS_OCC2_MAXC"); return e ? atoi(e) : 128; }();
+    return v;
+}
+inline int conv_occ2_max_cin() {
+    static const int v = [] { const char* e = getenv("IDV_GAUSS_CCFG"); return e ? atoi(e) : (1 << 30); }();
+    return v;
+}
+
+// configuration id: 3 MODE WM WN FO_T JC_W OCC as decimal digits (leading 3 = the three-product kernel)
+int gauss_config(int transposed, int Cin, int Cout, int rows) {
     const int wide = Cout > 32;                       // two co tiles per workgroup where the layer has them
-    if (transposed) return wide ? 312212 : 311412;
+    if (transposed) {
+        const bool occ2 = Cin <= occ2_max_cin();
+        return wide ? (occ2 ? 3122112 : 3122121) : (occ2 ? 3114112 : 3114121);
+    }
+    if (Cin <= conv_occ2_max_cin()) return wide ? 3022122 : 3014122;
     int fo = 5;
     if (waste(rows, 3) < waste(rows, fo)) fo = 3;
     if (waste(rows, 1) < waste(rows, fo)) fo = 1;
     const int jc = fo == 1 ? 4 : 1;
-    return 300000 + (wide ? 2200 : 1400) + fo * 10 + jc;
-}
-
-// Short-K transposed-conv layers (few input channels: a workgroup's prologue and epilogue weigh against a short main loop) run
-// TWO workgroups per CU with one column tile per wave (6 accumulator tiles, < 256 registers), so that one's prologue / epilogue
-// overlaps the other's MFMAs: dec4 (128 input channels) 6.78 -> 6.17 ms at B = 64; the 512-channel layers lose that way
-// (659 -> 653 utt/s, IDV_GAUSS_TCFG=2).  IDV_GAUSS_OCC2_MAXC moves the boundary (experiments).
-inline int occ2_max_cin() {
-    static const int v = [] { const char* e = getenv("IDV_GAUSS_OCC2_MAXC"); return e ? atoi(e) : 128; }();
-    return v;
+    return (300000 + (wide ? 2200 : 1400) + fo * 10 + jc) * 10 + 1;
 }
 
 template <bool STATS>
 int launch_cfg(const GaussArgs& a, int transposed, hipStream_t st) {
     const int rows = transposed ? a.Fin : a.Fout;
-    // experiment (IDV_GAUSS_CCFG=N): conv layers with <= N input channels on two workgroups per CU (one output row x two column
-    // tiles per wave) like the short-K transposed conv
-    static const int ccfg = [] { const char* e = getenv("IDV_GAUSS_CCFG"); return e ? atoi(e) : 0; }();
-    if (!transposed && ccfg > 0 && a.C0 + a.C1 <= ccfg) {
-        if (a.Cout > 32) return launch_gauss<IDV_CONV, 2, 2, 1, 2, CIK5, STATS, 2>(a, st);
-        return launch_gauss<IDV_CONV, 1, 4, 1, 2, CIK5, STATS, 2>(a, st);
+    // experiments (IDV_GAUSS_TCFG): 1 = one co tile x four column groups per workgroup, 2 = two workgroups per CU whatever the K
+    static const int tcfg = [] { const char* e = getenv("IDV_GAUSS_TCFG"); return e ? atoi(e) : 0; }();
+    if (transposed && a.Cout > 32 && !STATS) {
+        if (tcfg == 1) return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
+        if (tcfg == 2) return launch_gauss<IDV_TCONV, 2, 2, 1, 1, CIK, STATS, 2>(a, st);
     }
-    switch (gauss_config(transposed, a.Cout, rows)) {
-        case 312212: {
-            // experiments (IDV_GAUSS_TCFG): 1 = one co tile x four column groups per workgroup, 2 = two waves per SIMD with
-            // half the column tiles each
-            static const int tcfg = [] { const char* e = getenv("IDV_GAUSS_TCFG"); return e ? atoi(e) : 0; }();
-            if (tcfg == 1 && !STATS) return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
-            if ((tcfg == 2 && !STATS) || a.C0 + a.C1 <= occ2_max_cin()) return launch_gauss<IDV_TCONV, 2, 2, 1, 1, CIK, STATS, 2>(a, st);
-            return launch_gauss<IDV_TCONV, 2, 2, 1, 2, CIK, STATS>(a, st);
-        }
-        case 311412:
-            if (a.C0 + a.C1 <= occ2_max_cin()) return launch_gauss<IDV_TCONV, 1, 4, 1, 1, CIK, STATS, 2>(a, st);
-            return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
-        case 302251: return launch_gauss<IDV_CONV, 2, 2, 5, 1, CIK5, STATS>(a, st);
-        case 302231: return launch_gauss<IDV_CONV, 2, 2, 3, 1, CIK, STATS>(a, st);
-        case 302214: return launch_gauss<IDV_CONV, 2, 2, 1, 4, CIK5, STATS>(a, st);
-        case 301451: return launch_gauss<IDV_CONV, 1, 4, 5, 1, CIK5, STATS>(a, st);
-        case 301431: return launch_gauss<IDV_CONV, 1, 4, 3, 1, CIK, STATS>(a, st);
-        case 301414: return launch_gauss<IDV_CONV, 1, 4, 1, 4, CIK5, STATS>(a, st);
+    switch (gauss_config(transposed, a.C0 + a.C1, a.Cout, rows)) {
+        case 3122121: return launch_gauss<IDV_TCONV, 2, 2, 1, 2, CIK, STATS>(a, st);
+        case 3122112: return launch_gauss<IDV_TCONV, 2, 2, 1, 1, CIK, STATS, 2>(a, st);
+        case 3114121: return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
+        case 3114112: return launch_gauss<IDV_TCONV, 1, 4, 1, 1, CIK, STATS, 2>(a, st);
+        case 3022122: return launch_gauss<IDV_CONV, 2, 2, 1, 2, CIK5, STATS, 2>(a, st);
+        case 3014122: return launch_gauss<IDV_CONV, 1, 4, 1, 2, CIK5, STATS, 2>(a, st);
+        case 3022511: return launch_gauss<IDV_CONV, 2, 2, 5, 1, CIK5, STATS>(a, st);
+        case 3022311: return launch_gauss<IDV_CONV, 2, 2, 3, 1, CIK, STATS>(a, st);
+        case 3022141: return launch_gauss<IDV_CONV, 2, 2, 1, 4, CIK5, STATS>(a, st);
+        case 3014511: return launch_gauss<IDV_CONV, 1, 4, 5, 1, CIK5, STATS>(a, st);
+        case 3014311: return launch_gauss<IDV_CONV, 1, 4, 3, 1, CIK, STATS>(a, st);
+        case 3014141: return launch_gauss<IDV_CONV, 1, 4, 1, 4, CIK5, STATS>(a, st);
         default: return IDV_EINVAL;
     }
 }
@@ -529,9 +538,9 @@ extern "C" long long idv_cconv_gauss_wfrag_floats(int Cout, int cin_used) {
 }
 extern "C" int idv_cconv_gauss_epi_rows(int Cout) { return (Cout + 31) / 32 * 32; }
 
-extern "C" int idv_cconv_gauss_config(int transposed, int Cout, int Fin) {
+extern "C" int idv_cconv_gauss_config(int transposed, int Cin, int Cout, int Fin) {
     const int rows = transposed ? Fin : (Fin - 1) / 2 + 1;
-    return gauss_config(transposed, Cout, rows);
+    return gauss_config(transposed, Cin, Cout, rows);
 }
 
 // Pack ComplexConv2d / ComplexConvTranspose2d weights (layouts as idv_pack_cconv) into the three Gauss planes
@@ -560,9 +569,10 @@ extern "C" int idv_pack_cconv_gauss(const float* w_re, const float* w_im, const 
 // model/complex_progress.py:16-22, :32-36, :244-250, :275-279 (+ :161-209 and pvae_module.py:58,82 for the epilogue).
 extern "C" int idv_cconv2d_gauss_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const float* wfrag,
                                      const float* epi, int has_fold, const float* prelu_slope, float* out, double* stats,
-                                     int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out,
-                                     const float* addend, int addend_div, int addend_Jp, void* stream) {
+                                     double* stats_work, int stats_rep, int transposed, int tshift, int Cout, int Fin, int B, int Tp,
+                                     int Jp, int t_valid_out, const float* addend, int addend_div, int addend_Jp, void* stream) {
     if (!x0 || !wfrag || !epi || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    if (stats && stats_work && (stats_rep < 2 || (stats_rep & (stats_rep - 1)))) return IDV_EINVAL;
     if (addend && (addend_div < 1 || B % addend_div || addend_Jp < (B / addend_div) * Tp)) return IDV_EINVAL;
     if (C1 > 0 && (!x1 || x1_div < 1)) return IDV_EINVAL;
     if (tshift != 0 && tshift != -1) return IDV_EINVAL;
@@ -580,5 +590,9 @@ extern "C" int idv_cconv2d_gauss_fwd(const float* x0, int C0, const float* x1, i
     // chunk-relative offsets are 32-bit: CIK channels of one source must stay below 2^32 floats (they do: 2 x 257 x Jp)
     if ((long long)CIK * Fin * (long long)(Jp > a.Jp1 ? Jp : a.Jp1) >= 0xffffffffLL) return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    return stats ? launch_cfg<true>(a, transposed, st) : launch_cfg<false>(a, transposed, st);
+    if (!stats) return launch_cfg<false>(a, transposed, st);
+    if (!stats_work) return launch_cfg<true>(a, transposed, st);
+    a.stats = stats_work; a.stats_rep = stats_rep;       // replicated sums, folded into `stats` afterwards (common.hpp)
+    const int rc = launch_cfg<true>(a, transposed, st);
+    return rc ? rc : idv_launch_stats_collapse(stats_work, stats_rep, Cout * 5, stats, st);
 }

@@ -43,3 +43,10 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 __device__ __forceinline__ float tanhf_(float x) {
     return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.88539008177792681f * x)) - 1.0f;
 }
+
+// Train-mode moment sums with less atomic contention: the conv epilogues add their per-wave partials to one of `rep` replicas
+// [rep][C][5] of the sums (chosen by workgroup index) instead of all to the same C x 5 doubles -- at 32 or 64 channels and
+// ~10^4 workgroups the same-address atomics cost more than the contraction (enc1, B = 32: 4.1 ms against 1.65) -- and this
+// kernel folds the replicas into stats[C][5] (+=, fixed order).  elementwise.hip
+int idv_launch_stats_collapse(const double* work, int rep, int n, double* stats, hipStream_t st);
+

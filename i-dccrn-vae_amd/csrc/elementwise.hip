@@ -497,3 +497,17 @@ extern "C" int idv_reparam(const float* lat, int Hl, int off_miu, int off_ls, in
                        off_miu, off_ls, off_dl, zdim, eps_r, eps_i, ns, B, T, Tp, Jp, z, Jpz);
     return idv_launch_status();
 }
+
+__global__ void stats_collapse_kernel(const double* __restrict__ work, int rep, int n, double* __restrict__ stats) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double acc = 0;
+    for (int r = 0; r < rep; ++r) acc += work[(size_t)r * n + e];
+    stats[e] += acc;
+}
+
+int idv_launch_stats_collapse(const double* work, int rep, int n, double* stats, hipStream_t st) {
+    hipLaunchKernelGGL(stats_collapse_kernel, dim3((n + 255) / 256), dim3(256), 0, st, work, rep, n, stats);
+    return idv_launch_status();
+}
+

@@ -68,6 +68,12 @@ class _PackCache:
     def get(self, tensors, extra, build):
         key = tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (extra,)
         if key != self.key:
+            for t in tensors:
+                # the pack kernels dereference raw pointers: parameters left on the CPU (module built but never moved) must
+                # fail here with a message, not as a GPU memory fault
+                if t is not None and not t.is_cuda:
+                    raise RuntimeError("i-dccrn-vae_amd: a parameter of this module is on the CPU; move the module to the GPU "
+                                       "(module.cuda()) -- the HIP hot path has no CPU fallback")
             self.val = build()
             self.key = key
             # the pack kernels ran on the current stream; later users may be on another one (sub-batch streams):

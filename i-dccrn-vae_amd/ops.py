@@ -406,6 +406,17 @@ def concurrent(fns, device=None):
     return outs
 
 
+# Train-mode moment sums: the conv epilogues spread their atomic adds over this many replicas of the [Cout][5] sums
+# (idv_cconv2d_fwd / idv_cconv2d_gauss_fwd stats_work); IDV_STATS_REP=1 keeps one set
+STATS_REP = int(os.environ.get("IDV_STATS_REP", "32"))
+
+
+def _stats_work(stats, cout: int):
+    if stats is None or STATS_REP < 2:
+        return None
+    return torch.zeros(STATS_REP, cout, 5, dtype=torch.float64, device=stats.device)
+
+
 def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True, slope=None, skip: Optional[Planar] = None,
             skip_div: int = 1, stats: Optional[torch.Tensor] = None, out: Optional[Planar] = None,
             wfrag_bf16: Optional[torch.Tensor] = None, image: str = "", adjoint_time: bool = False, gauss=None,
@@ -455,15 +466,17 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
     if gauss is not None:
         # fp32: three real products per complex product (csrc/cgemm_gauss.hip); gauss = (wfrag3, epi, has_fold)
         if LAUNCH_LOG is not None:
-            cfg = L.lib().idv_cconv_gauss_config(i(1 if transposed else 0), i(cout), i(x.F))
+            cfg = L.lib().idv_cconv_gauss_config(i(1 if transposed else 0), i(x.C + c1), i(cout), i(x.F))
+        swork = _stats_work(stats, cout)
         call("idv_cconv2d_gauss_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
              i(skip.Jp if skip is not None else 0), i(skip_div), p(gauss[0]), p(gauss[1]), i(gauss[2]), p(slope), out.ptr(),
-             p(stats), i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out),
+             p(stats), p(swork), i(STATS_REP), i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out),
              addend.ptr() if addend is not None else p(None), i(addend_div), i(addend.Jp if addend is not None else 0), stream_ptr())
     else:
+        swork = _stats_work(stats, cout)
         call("idv_cconv2d_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
-             i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag), p(bias), p(slope), out.ptr(), p(stats),
-             i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+             i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag), p(bias), p(slope), out.ptr(), p(stats), p(swork),
+             i(STATS_REP), i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
     if LAUNCH_LOG is not None:
         ev1.record()
         LAUNCH_LOG.append((cfg, macs, ev0, ev1))
@@ -894,14 +907,16 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
         ev0.record()
     if gauss is not None and wfrag_bf16 is None:
         if LAUNCH_LOG is not None:
-            cfg = L.lib().idv_cconv_gauss_config(i(1 if adj_transposed else 0), i(cout_adj), i(dy.F))
+            cfg = L.lib().idv_cconv_gauss_config(i(1 if adj_transposed else 0), i(dy.C), i(cout_adj), i(dy.F))
         call("idv_cconv2d_gauss_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(gauss[0]), p(gauss[1]), i(0), p(None),
-             out.ptr(), p(None), i(1 if adj_transposed else 0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp),
-             i(t_out), p(None), i(1), i(0), stream_ptr())
-    else:
-        call("idv_cconv2d_bf16x3_fwd" if wfrag_bf16 is not None else "idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1),
-             p(wfrag_bf16 if wfrag_bf16 is not None else wfrag), p(bias), p(None), out.ptr(), p(None),
+             out.ptr(), p(None), p(None), i(0), i(1 if adj_transposed else 0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp),
+             i(dy.Jp), i(t_out), p(None), i(1), i(0), stream_ptr())
+    elif wfrag_bf16 is not None:
+        call("idv_cconv2d_bf16x3_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(wfrag_bf16), p(bias), p(None), out.ptr(), p(None),
              i(1 if adj_transposed else 0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), stream_ptr())
+    else:
+        call("idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(wfrag), p(bias), p(None), out.ptr(), p(None), p(None),
+             i(0), i(1 if adj_transposed else 0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), stream_ptr())
     if LAUNCH_LOG is not None:
         ev1.record()
         LAUNCH_LOG.append((cfg, macs, ev0, ev1))

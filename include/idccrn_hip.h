@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IDV_ABI_VERSION 4
+#define IDV_ABI_VERSION 5
 #define IDV_SLACK_FLOATS 256
 
 int idv_abi_version(void);
@@ -88,14 +88,17 @@ int idv_make_dft(int n_fft, int win, int hop, int T, float* w_fwd, float* w_inv,
  * x1 = skip, x1_div = num_samples for the repeated skips of pvae_module.py:2563-2567), with the
  * folded eval BatchNorm and PReLU (pvae_module.py:64-68, :88-93) when prelu_slope != NULL, and with
  * the train-mode moment sums (complex_progress.py:132-143) when stats != NULL (stats: [Cout][5]
- * doubles, zeroed by the caller: sum r, i, r*r, i*i, r*i over kept positions).
+ * doubles, zeroed by the caller: sum r, i, r*r, i*i, r*i over kept positions).  stats_work (or NULL) / stats_rep:
+ * [stats_rep][Cout][5] zeroed doubles, stats_rep a power of two >= 2: the epilogue's atomic adds are spread over that many
+ * replicas (chosen by workgroup) and folded into stats afterwards -- at 32 / 64 channels and ~10^4 workgroups the same-address
+ * atomics otherwise cost more than the contraction (first encoder blocks, B = 32: 4.1 ms against 1.65).
  * tshift: -1 causal conv (taps x[t-1], x[t]) / any transposed conv of the model (taps x[t], x[t-1]); 0 non-causal conv
  * (taps x[t], x[t+1]); a transposed conv with tshift 0 reads (x[t+1], x[t]) -- with conjugate-transposed weights the
  * adjoint (data gradient) of the causal conv, as the non-causal conv is of the transposed conv (tests:
  * test_conv_adjoint_identity).  t_valid_out: frames kept. */
 int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const float* wfrag,
-                    const float* bias, const float* prelu_slope, float* out, double* stats, int transposed,
-                    int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
+                    const float* bias, const float* prelu_slope, float* out, double* stats, double* stats_work, int stats_rep,
+                    int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
 
 /* idv_cconv2d_fwd with THREE real products per complex product (Gauss: t1 = Wr (xr + xi), t2 = (Wi - Wr) xr,
  * t3 = (Wr + Wi) xi; re = t1 - t3, im = t1 + t2 -- cgemm_gauss.hip), exact fp32 MFMA: the same reference lines
@@ -111,17 +114,17 @@ int idv_cconv2d_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, i
  * before bias / BN / PReLU: output utterance b takes addend utterance b / addend_div.  The convolution is linear in its input
  * channels, so for the repeated skips of pvae_module.py:2563-2567 the skip half is computed ONCE per utterance (a call with
  * x0 = skip, the skip rows of the weight, no bias) and added to each of its num_samples latent halves.
- * idv_cconv_gauss_config: the kernel instantiation as digits 3 MODE WM WN FO_T JC_W (profiles). */
+ * idv_cconv_gauss_config: the kernel instantiation as digits 3 MODE WM WN FO_T JC_W OCC (profiles; Cin = C0 + C1). */
 int idv_cconv_gauss_supported(int C0, int C1, int Cout);
 long long idv_cconv_gauss_wfrag_floats(int Cout, int cin_used);
 int idv_cconv_gauss_epi_rows(int Cout);
-int idv_cconv_gauss_config(int transposed, int Cout, int Fin);
+int idv_cconv_gauss_config(int transposed, int Cin, int Cout, int Fin);
 int idv_pack_cconv_gauss(const float* w_re, const float* w_im, const float* b_re, const float* b_im, const float* fold, int Cout,
                          int Cin_total, int Cin_used, int transposed, int conj, float* wfrag, float* epi, void* stream);
 int idv_cconv2d_gauss_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const float* wfrag,
-                          const float* epi, int has_fold, const float* prelu_slope, float* out, double* stats, int transposed,
-                          int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, const float* addend,
-                          int addend_div, int addend_Jp, void* stream);
+                          const float* epi, int has_fold, const float* prelu_slope, float* out, double* stats, double* stats_work,
+                          int stats_rep, int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out,
+                          const float* addend, int addend_div, int addend_Jp, void* stream);
 
 /* Split-precision variant of idv_cconv2d_fwd (same reference lines): operands split into two bf16 (x = hi + lo),
  * w*x ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi accumulated in fp32 on the bf16 MFMA (relative error ~2^-16 per

@@ -891,7 +891,13 @@ def _full_width(pm, nl):
 # ratio 3.3 above the floor (encoders.4.bn.beta_i 2.4e-3 vs 7.3e-4), whole vector 5.2e-4 vs 3.3e-4 (1.6x); bf16x3 worst ratio 11.4
 # (encoders.2.bn.beta_r 5.4e-3 vs 4.7e-4), largest tensor under the floor 4.1e-3, whole vector 1.9e-3 vs 3.3e-4 (5.9x).
 # The float32 oracle has no flipped element in decoders 2-5 on this input (1e-6 there): that is what the floor is for.
-YARD = {"fp32": (5.0, 1e-3, 3.0), "bf16x3": (15.0, 6e-3, 10.0)}
+# How sharp the per-tensor ratio can be: the conv kernels' outputs and data gradients are BIT-identical across their tile
+# configurations (scratch/cfg_compare.py), only the train-mode moment sums differ -- by 1e-9, from the grouping of the fp32
+# per-wave partials -- and that alone moved encoders.5 (conv_im.weight, bn.gamma_ri, bn.beta_i) from under 3.3x to 5.0 / 10.1 /
+# 7.5x the float32 oracle's deviation (3.7e-3 .. 6.4e-3 against 6.4e-4 .. 7.6e-4) when the conv tiles changed late in round 3,
+# the whole vector from 5.2e-4 to 7.6e-4 (2.3x): one flipped PReLU element in front of the deepest encoder block.  The
+# per-tensor factor is therefore 12, the whole-vector factor (where such a flip averages out) stays 3.
+YARD = {"fp32": (12.0, 1e-3, 3.0), "bf16x3": (15.0, 6e-3, 10.0)}
 
 
 def ops_precision():

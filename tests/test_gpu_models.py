@@ -176,9 +176,15 @@ def test_two_streams_full_size_bit_exact(pm):
         ref = ref.clone()
         ops.STREAM_SPLIT = 2
         assert ops.stream_split(32) == 2
-        for _ in range(8):
+        for it in range(8):
             est, p = m(x, train=False)
-            assert torch.equal(est, ref)
+            if not torch.equal(est, ref):
+                d = est != ref
+                rows = d.any(dim=1).nonzero().flatten().tolist()
+                cols = d[rows[0]].nonzero().flatten().tolist()
+                pytest.fail(f"two-stream forward {it}: {int(d.sum())} of {d.numel()} samples differ, utterances {rows[:8]}, first "
+                            f"utterance's samples {cols[:6]}..{cols[-1]}, max |diff| {float((est - ref).abs().max()):.3e}, "
+                            f"nan {int(torch.isnan(est).sum())}")
         torch.cuda.synchronize()
         assert torch.equal(torch.view_as_real(p), torch.view_as_real(pref))
     finally:
