@@ -477,7 +477,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((FO_T == 3 && JC_W == 1 && MT_W == 1)
                     float t = st[q][s];
 #pragma unroll
                     for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-                    if (l31 == 0 && m < a.M) atomicAdd(&a.stats[(size_t)(m >> 1) * 5 + s], (double)t);
+                    if (l31 == 0 && m < a.M)
+                        atomicAdd(&a.stats[((size_t)(a.stats_rep > 1 ? (blockIdx.x & (a.stats_rep - 1)) : 0) * a.Cout + (m >> 1)) * 5 + s],
+                                  (double)t);
                 }
             }
         }
@@ -597,9 +599,10 @@ extern "C" int idv_pack_cconv_bf16_adjoint(const float* w_re, const float* w_im,
 
 extern "C" int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div,
                                       const void* wfrag_bf16, const float* bias, const float* prelu_slope, float* out,
-                                      double* stats, int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp,
-                                      int t_valid_out, void* stream) {
+                                      double* stats, double* stats_work, int stats_rep, int transposed, int tshift, int Cout, int Fin,
+                                      int B, int Tp, int Jp, int t_valid_out, void* stream) {
     if (!x0 || !wfrag_bf16 || !bias || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    if (stats && stats_work && (stats_rep < 2 || (stats_rep & (stats_rep - 1)))) return IDV_EINVAL;
     if (!idv_cconv_bf16_supported(transposed, C0, C1, x1_div < 1 ? 1 : x1_div, Cout)) return IDV_EINVAL;
     if (C1 > 0 && (!x1 || Jp1 != Jp || (reinterpret_cast<uintptr_t>(x1) & 15))) return IDV_EINVAL;
     if ((Jp % 4) || (reinterpret_cast<uintptr_t>(x0) & 15) || (tshift != 0 && tshift != -1)) return IDV_EINVAL;
@@ -616,6 +619,9 @@ extern "C" int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, 
     const int rows = transposed ? Fin : a.Fout;
     const bool fo5 = waste(rows, 5) <= waste(rows, 3);
     const bool wide = a.M >= 128;                            // 4 row tiles per workgroup when the layer has them
+    const bool repl = stats && stats_work;                   // replicated moment sums, folded into `stats` afterwards (common.hpp)
+    if (repl) { a.stats = stats_work; a.stats_rep = stats_rep; }
+    const int rc = [&]() -> int {
     // measured (B = 64): the conv with 3 row tiles runs best at 2 waves/SIMD with 32-column tiles (JC_W = 1),
     // the transposed conv (12 accumulator tiles) at 1 wave/SIMD with 64-column tiles
     // conv layers with >= 256 rows: two row tiles per wave (256-row workgroups) halve the staging per MFMA
@@ -638,6 +644,8 @@ extern "C" int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, 
         IDV_BF16_DISPATCH(IDV_CONV)
     }
 #undef IDV_BF16_DISPATCH
+    }();
+    return (rc || !repl) ? rc : idv_launch_stats_collapse(stats_work, stats_rep, Cout * 5, stats, st);
 }
 
 // <MODE, WM, WN, FO_T, JC_W, MT_W, IMGIN, AD> (as decimal digits) of the instantiation idv_cconv2d_img_fwd launches:
@@ -721,10 +729,12 @@ extern "C" int idv_cconv2d_img_fwd(int src_is_image, const void* x0_img, long lo
 // idv_cconv2d_bf16x3_fwd, whose staging splits the fp32 patch in registers (1.5x slower).  One row tile per wave (the
 // two-tile form keeps no registers for the moments).
 extern "C" int idv_cconv2d_img_train_fwd(const void* x0_img, long long lo_off0, int C0, const void* x1_img, long long lo_off1, int C1,
-                                         const void* wfrag_bf16, const float* bias, float* out_planar, double* stats, int transposed,
-                                         int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream) {
+                                         const void* wfrag_bf16, const float* bias, float* out_planar, double* stats,
+                                         double* stats_work, int stats_rep, int transposed, int Cout, int Fin, int B, int Tp, int Jp,
+                                         int t_valid_out, void* stream) {
     if (!x0_img || !wfrag_bf16 || !bias || !out_planar || !stats || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1)
         return IDV_EINVAL;
+    if (stats_work && (stats_rep < 2 || (stats_rep & (stats_rep - 1)))) return IDV_EINVAL;
     if (!idv_cconv_bf16_supported(transposed, C0, C1, 1, Cout)) return IDV_EINVAL;
     if (C1 > 0 && (!x1_img || (reinterpret_cast<uintptr_t>(x1_img) & 15))) return IDV_EINVAL;
     if (reinterpret_cast<uintptr_t>(x0_img) & 15) return IDV_EINVAL;
@@ -743,10 +753,14 @@ extern "C" int idv_cconv2d_img_train_fwd(const void* x0_img, long long lo_off0, 
     const int rows = transposed ? Fin : a.Fout;
     const bool fo5 = waste(rows, 5) <= waste(rows, 3);
     const bool wide = a.M >= 128;
-    if (!transposed) {
-        if (wide) return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 1, true, 1, true, IDV_AD>(a, st);
-        return fo5 ? launch_bf16<IDV_CONV, 2, 2, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_CONV, 2, 2, 3, 1, true, 1, true, IDV_AD>(a, st);
-    }
-    if (wide) return fo5 ? launch_bf16<IDV_TCONV, 4, 1, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_TCONV, 4, 1, 3, 2, true, 1, true, IDV_AD>(a, st);
-    return fo5 ? launch_bf16<IDV_TCONV, 2, 2, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_TCONV, 2, 2, 3, 1, true, 1, true, IDV_AD>(a, st);
+    if (stats_work) { a.stats = stats_work; a.stats_rep = stats_rep; }
+    const int rc = [&]() -> int {
+        if (!transposed) {
+            if (wide) return fo5 ? launch_bf16<IDV_CONV, 4, 1, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_CONV, 4, 1, 3, 1, true, 1, true, IDV_AD>(a, st);
+            return fo5 ? launch_bf16<IDV_CONV, 2, 2, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_CONV, 2, 2, 3, 1, true, 1, true, IDV_AD>(a, st);
+        }
+        if (wide) return fo5 ? launch_bf16<IDV_TCONV, 4, 1, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_TCONV, 4, 1, 3, 2, true, 1, true, IDV_AD>(a, st);
+        return fo5 ? launch_bf16<IDV_TCONV, 2, 2, 5, 1, true, 1, true, IDV_AD>(a, st) : launch_bf16<IDV_TCONV, 2, 2, 3, 1, true, 1, true, IDV_AD>(a, st);
+    }();
+    return (rc || !stats_work) ? rc : idv_launch_stats_collapse(stats_work, stats_rep, Cout * 5, stats, st);
 }

@@ -456,9 +456,10 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
     if wfrag_bf16 is not None:
         if LAUNCH_LOG is not None:
             cfg = -(1000000 + L.lib().idv_cconv_bf16_config(i(1 if transposed else 0), i(cout), i(x.F)))
+        swork = _stats_work(stats, cout)
         call("idv_cconv2d_bf16x3_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1),
-             i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag_bf16), p(bias), p(slope), out.ptr(), p(stats),
-             i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+             i(skip.Jp if skip is not None else 0), i(skip_div), p(wfrag_bf16), p(bias), p(slope), out.ptr(), p(stats), p(swork),
+             i(STATS_REP), i(1 if transposed else 0), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
         if LAUNCH_LOG is not None:
             ev1.record()
             LAUNCH_LOG.append((cfg, macs, ev0, ev1))
@@ -529,8 +530,9 @@ def cconv2d_img_train(x: Image, wfrag_bf16, bias, cout: int, stats, *, transpose
         macs = 4 * (x.C + c1) * cout * 10 * x.B * x.T * (x.F if transposed else Fout)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+    swork = _stats_work(stats, cout)
     call("idv_cconv2d_img_train_fwd", x.ptr(), ll(x.lo_slots), i(x.C), skip.ptr() if skip is not None else p(None),
-         ll(skip.lo_slots if skip is not None else 0), i(c1), p(wfrag_bf16), p(bias), out.ptr(), p(stats),
+         ll(skip.lo_slots if skip is not None else 0), i(c1), p(wfrag_bf16), p(bias), out.ptr(), p(stats), p(swork), i(STATS_REP),
          i(1 if transposed else 0), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(x.T), stream_ptr())
     if LAUNCH_LOG is not None:
         ev1.record()
@@ -913,7 +915,8 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
              i(dy.Jp), i(t_out), p(None), i(1), i(0), stream_ptr())
     elif wfrag_bf16 is not None:
         call("idv_cconv2d_bf16x3_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(wfrag_bf16), p(bias), p(None), out.ptr(), p(None),
-             i(1 if adj_transposed else 0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), stream_ptr())
+             p(None), i(0), i(1 if adj_transposed else 0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out),
+             stream_ptr())
     else:
         call("idv_cconv2d_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(wfrag), p(bias), p(None), out.ptr(), p(None), p(None),
              i(0), i(1 if adj_transposed else 0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), stream_ptr())

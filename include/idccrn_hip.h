@@ -138,8 +138,9 @@ int idv_cconv_bf16_config(int transposed, int Cout, int Fin);   /* <MODE, WM, WN
 int idv_pack_cconv_bf16(const float* w_re, const float* w_im, const float* fold, int Cout, int Cin_total, int Cin_used,
                         int transposed, void* wfrag, void* stream);
 int idv_cconv2d_bf16x3_fwd(const float* x0, int C0, const float* x1, int C1, int Jp1, int x1_div, const void* wfrag_bf16,
-                           const float* bias, const float* prelu_slope, float* out, double* stats, int transposed,
-                           int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
+                           const float* bias, const float* prelu_slope, float* out, double* stats, double* stats_work,
+                           int stats_rep, int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out,
+                           void* stream);   /* stats_work / stats_rep: as idv_cconv2d_fwd */
 
 /* Split image: the inter-layer activation format of the bf16x3 path (eval mode).  bf16 elements,
  *   image[hi|lo][octet o][F][Jp][8],  element e of octet o = planar channel cc = 8*o + e = 2*ci + ri,
@@ -158,8 +159,8 @@ int idv_cconv2d_fwd_img(const float* x0, int C0, const float* x1, int C1, int Jp
 /* training forward from split images (bf16x3 training mode): planar fp32 y + the per-channel moments, as idv_cconv2d_fwd with
  * `stats`; sources as idv_cconv2d_img_fwd with src_is_image = 1 */
 int idv_cconv2d_img_train_fwd(const void* x0_img, long long lo_off0, int C0, const void* x1_img, long long lo_off1, int C1,
-                              const void* wfrag_bf16, const float* bias, float* out_planar, double* stats, int transposed, int Cout,
-                              int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
+                              const void* wfrag_bf16, const float* bias, float* out_planar, double* stats, double* stats_work,
+                              int stats_rep, int transposed, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, void* stream);
 int idv_cconv_img_config(int src_is_image, int transposed, int Cin, int Cout, int Fin);   /* template digits <MODE, WM, WN,
                         FO_T, JC_W, MT_W, IMGIN, AD> of the cgemm_bf16_kernel idv_cconv2d_img_fwd launches (profiles) */
 int idv_planar_to_image(const float* x, int C, int F, int J, int Jp, void* img, long long lo_off_elems, void* stream);
