@@ -93,6 +93,23 @@ def test_dccrn_vs_oracle_other_length(pm):
     assert relerr(torch.view_as_real(p2).cpu(), O.stft(o_c2, NFFT, HOP, WIN)) < WAVE_TOL
 
 
+def test_cpu_parameters_fail_loudly(pm):
+    """A module whose parameters were never moved to the GPU: the pack kernels would dereference host pointers (a GPU memory
+    fault); the weight caches refuse first, with a message.  CPU inputs are refused as well (no CPU fallback)."""
+    np_ = O.net_params(True, 4)
+    m = pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None)
+    m.load_state_dict(O.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 5))
+    m.cpu()
+    x = torch.randn(1, 1600) * 0.1
+    with pytest.raises(RuntimeError, match="on the CPU"):
+        m(x.cuda(), train=False)
+    m.cuda()
+    with pytest.raises(RuntimeError):
+        m(x, train=False)
+    y, _ = m(x.cuda(), train=False)
+    assert torch.isfinite(y).all()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_dccrn_stream_split_is_bit_exact(pm, precision):
     """Eval sub-batches on separate HIP streams (DCCRN_.forward) vs one stream: per-utterance results identical,
