@@ -408,20 +408,31 @@ class LstmFn(torch.autograd.Function):
         # ---- layer 1
         dh1 = new(4 * TBH)
         call("idv_lstm_uncombine", do.ptr(), i(H), i(B), i(T), i(Tp), i(Jp), p(dh1), st())
-        call("idv_lstm_bptt", p(G1), ll(2 * T * B * 4 * H), ll(T * B * 4 * H), i(4 * H), p(c1), p(dh1), p(whhT(1)), i(H), i(B),
-             i(T), p(bw), st())
+        # H = 128: the BPTT of BOTH layers in one cooperative launch, layer 0 a step behind layer 1 and dh0 = dG1 W_ih1 inside
+        # the recurrence (csrc/lstm_bptt_stack2_f32.hip; exact fp32 in either arithmetic mode)
+        fused = ops.LSTM_STACK2 and ops.LSTM_PERSISTENT and bool(L.lib().idv_lstm_bptt_stack2_supported(i(H), i(B)))
+        if fused:
+            wihT1 = new(2 * 4 * H * H)
+            call("idv_pack_lstm_hh_bwd", p(P["lstm_re.weight_ih_l1"]), p(P["lstm_im.weight_ih_l1"]), i(H), p(wihT1), st())
+            bw2 = new((int(ops._ll_fn("idv_lstm_bptt_stack2_work_bytes")(i(H), i(B))) + 3) // 4)
+            call("idv_lstm_bptt_stack2", p(G1), p(G0), ll(T * B * 8 * H), ll(4 * H), i(8 * H), p(c1), p(c0), p(dh1), p(whhT(1)),
+                 p(wihT1), p(whhT(0)), i(H), i(B), i(T), p(bw2), st())
+        else:
+            call("idv_lstm_bptt", p(G1), ll(2 * T * B * 4 * H), ll(T * B * 4 * H), i(4 * H), p(c1), p(dh1), p(whhT(1)), i(H), i(B),
+                 i(T), p(bw), st())
         h0p = [planar_of_rows(h0[r * TBH:(r + 1) * TBH], H, 0, H) for r in range(4)]
         h1p = [planar_of_rows(h1[r * TBH:(r + 1) * TBH], H, 0, H) for r in range(4)]
         dwih1, dwhh1, db1 = new(8 * H, H), new(8 * H, H), new(8 * H)
-        dh0 = new(4 * TBH)
+        dh0 = None if fused else new(4 * TBH)
         # bf16x3 training mode: the two data-gradient contractions of the projections (dh0 = dG1 W_ih1, dx = dG0 W_ih0) on the
         # split-bf16 point-wise kernel, fed with K-major split images of the gate gradients (the fp32 form was 17 % of the
         # NSVAE train step)
         bf16 = ops.PRECISION == "bf16x3" and (4 * H) % 64 == 0 and H >= 64
         zb = torch.zeros(max(H, K), dtype=torch.float32, device=dev) if bf16 else None
         for s in range(2):
-            w_colp_T = P[f"{'lstm_im' if s else 'lstm_re'}.weight_ih_l1"][perm].t().contiguous()     # [H][4H colp]
-            wT = ops.pack_pw_bf16(w_colp_T) if bf16 else ops.pack_pw(w_colp_T, None)
+            if not fused:
+                w_colp_T = P[f"{'lstm_im' if s else 'lstm_re'}.weight_ih_l1"][perm].t().contiguous()     # [H][4H colp]
+                wT = ops.pack_pw_bf16(w_colp_T) if bf16 else ops.pack_pw(w_colp_T, None)
             for k, run in enumerate((s, 2 + s)):
                 dG1p = planar_of_rows(G1[run * 4 * TBH:(run + 1) * 4 * TBH], 4 * H, 0, 4 * H)
                 acc = k > 0
@@ -431,14 +442,17 @@ class LstmFn(torch.autograd.Function):
                              accumulate=acc)
                 call("idv_lstm_bias_grad", p(dG1p), i(H), i(Jp), i(J), i(1 if acc else 0), p(db1[s * 4 * H:(s + 1) * 4 * H]), st())
                 # gradient arriving at layer 0's output: dG1 W_ih1, written row-major [T*B][H]
-                if bf16:
+                if fused:
+                    pass
+                elif bf16:
                     kimg = ops.KImage.from_planes(p(dG1p), 4 * H, J, Jp, dev, pad_to=64)
                     ops.pw_bf16x3_rows(kimg, 4 * H, wT, zb, H, H, B, T, Tp, p(dh0[run * TBH:(run + 1) * TBH]))
                 else:
                     ops.pw_gemm(p(dG1p), 4 * H, wT[0], wT[1], H, B, Tp, Jp, T, p(dh0[run * TBH:(run + 1) * TBH]), swap=True, ldo=H)
         # ---- layer 0
-        call("idv_lstm_bptt", p(G0), ll(T * B * 8 * H), ll(4 * H), i(8 * H), p(c0), p(dh0), p(whhT(0)), i(H), i(B), i(T),
-             p(bw), st())
+        if not fused:
+            call("idv_lstm_bptt", p(G0), ll(T * B * 8 * H), ll(4 * H), i(8 * H), p(c0), p(dh0), p(whhT(0)), i(H), i(B), i(T),
+                 p(bw), st())
         dwih0, dwhh0, db0 = new(8 * H, K), new(8 * H, H), new(8 * H)
         dx = ops.like(x) if ctx.needs_input_grad[2] else None
         if dx is not None:

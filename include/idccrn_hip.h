@@ -538,6 +538,18 @@ int idv_lstm_bptt(float* gates, long long g_run_z, long long g_run_s, int ldg, c
  * dc in registers, dA_t exchanged with the fence-free hand-off of idv_lstm_rec_pers); idv_lstm_bptt dispatches to it when
  * idv_lstm_bptt_coop_supported (IDV_LSTM_BPTT_COOP=0 keeps the per-step launches).  work: idv_lstm_bptt_coop_work_bytes. */
 int idv_lstm_bptt_coop_supported(int H, int B);
+/* BPTT of BOTH H = 128 layers in one cooperative launch (lstm_bptt_stack2_f32.hip; the backward twin of idv_lstm_stack2_f32):
+ * layer 0 runs one step behind layer 1 and contracts dh0[t] = dA1[t] W_ih1 inside its recurrence, so the dh0 buffer and its
+ * GEMM disappear.  g1: [run][T*B][4H] activated gates of layer 1 -> gate gradients; g0 (+ g0_run_z, g0_run_s, ldg0): layer 0's,
+ * addressed as in idv_lstm_bptt; c1, c0: cell states [4][T*B][H]; dhout1: gradient arriving at layer 1's output; whhT1, wihT1,
+ * whhT0: idv_pack_lstm_hh_bwd of weight_hh_l1, weight_ih_l1 ([4H][H] as well), weight_hh_l0; work:
+ * idv_lstm_bptt_stack2_work_bytes bytes, 16-byte aligned.  Supported: H == 128, 32 * ceil(B/16) <= idv_coop_max_workgroups()
+ * (IDV_LSTM_BPTT_STACK2=0 turns it off). */
+int idv_lstm_bptt_stack2_supported(int H, int B);
+long long idv_lstm_bptt_stack2_work_bytes(int H, int B);
+int idv_lstm_bptt_stack2(float* g1, float* g0, long long g0_run_z, long long g0_run_s, int ldg0, const float* c1, const float* c0,
+                         const float* dhout1, const float* whhT1, const float* wihT1, const float* whhT0, int H, int B, int T,
+                         void* work, void* stream);
 long long idv_lstm_bptt_coop_work_bytes(int H, int B);
 int idv_lstm_bptt_coop(float* gates, long long g_run_z, long long g_run_s, int ldg, const float* cstates, const float* dhout,
                        const float* whhT, int H, int B, int T, void* work, void* stream);
