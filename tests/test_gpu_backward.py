@@ -287,6 +287,59 @@ def _clstm_grads(ops, cp, H, I, T, B, ftol, gtol):
         check(k, p_.grad, sd[k].grad, gtol)
 
 
+def test_cooperative_bptt_times_out_instead_of_hanging(ops, cp):
+    """Safety net of the cooperative BPTT (lstm_bptt_stack2_f32.hip: both H = 128 layers in one launch): with one layer-1
+    workgroup withheld (IDV_COOP_FAULT=1) every spin runs into its bound, both layers drain, the gate gradients are poisoned
+    with NaN -- the backward returns within seconds, the status word says -3 -- and the next forward + backward is correct."""
+    import os
+    import time
+    H, I, T, B = 128, 64, 12, 5
+    dev = "cuda"
+    g = torch.Generator().manual_seed(13)
+    m = cp.ComplexLSTM(I, H, dev, num_layers=2)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.copy_(rnd(g, *p_.shape, scale=1.0 / H ** 0.5))
+    m = m.to(dev)
+    x = rnd(g, T, B, I, 2)
+    lib = ops.L.lib()
+    assert lib.idv_lstm_bptt_stack2_supported(H, B)
+
+    def run():
+        for p_ in m.parameters():
+            p_.grad = None
+        xp = ops.Planar.from_tensor5(x.permute(1, 2, 0, 3).unsqueeze(2).to(dev))
+        xp.buf.requires_grad_(True)
+        with torch.enable_grad():
+            m.forward_planar(xp).buf.sum().backward()
+        torch.cuda.synchronize()
+        # (the valid region: slack and row padding of the gradient buffer are never written)
+        return ops.rewrap(xp.buf.grad, xp).tensor5().clone(), [p_.grad.clone() for p_ in m.parameters()]
+
+    good = run()
+    try:
+        with torch.enable_grad():
+            xp = ops.Planar.from_tensor5(x.permute(1, 2, 0, 3).unsqueeze(2).to(dev))
+            xp.buf.requires_grad_(True)
+            loss = m.forward_planar(xp).buf.sum()
+            torch.cuda.synchronize()
+            os.environ["IDV_COOP_FAULT"] = "1"
+            t0 = time.perf_counter()
+            loss.backward()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    finally:
+        os.environ.pop("IDV_COOP_FAULT", None)
+    assert dt < 5.0, dt
+    assert lib.idv_coop_last_status(1) == -3                    # reported through the C ABI (and cleared)
+    assert torch.isnan(xp.buf.grad).any()
+    again = run()
+    assert lib.idv_coop_last_status(1) == 0
+    assert torch.isfinite(again[0]).all() and torch.equal(again[0], good[0])
+    for a_, b_ in zip(again[1], good[1]):
+        assert torch.equal(a_, b_)
+
+
 # ----------------------------------------------------------------------------- dense, mask, STFT / ISTFT
 def test_cdense_grads(ops, cp):
     g = torch.Generator().manual_seed(5)
