@@ -242,7 +242,8 @@ def _conv_block_grads(ops, pm, transposed, cin, cout, F, T, B, skip_c, bn, ftol,
 
 # ----------------------------------------------------------------------------- complex LSTM (BPTT)
 @pytest.mark.parametrize("H,I,T,B", [(16, 20, 7, 3), (128, 64, 12, 5), (128, 160, 30, 18), (48, 32, 6, 2), (96, 160, 9, 17),
-                                     (384, 64, 5, 3), (768, 64, 9, 20), (384, 128, 12, 33)])
+                                     (384, 64, 5, 3), (768, 64, 9, 20), (384, 128, 12, 33),
+                                     (128, 64, 1, 3), (128, 64, 2, 17), (128, 64, 5, 100)])     # one / two frames, 7 tiles
 def test_clstm_grads(ops, cp, H, I, T, B):
     _clstm_grads(ops, cp, H, I, T, B, 2e-5, GTOL)
 
