@@ -336,7 +336,8 @@ def kernel_name(cfg_id):
     if 3000000 <= cfg_id < 4000000:       # idv_cconv_gauss_config digits 3 MODE WM WN FO_T JC_W OCC
         d = str(cfg_id)
         occ = int(d[6])
-        cik = 2 if (d[1] == "0" and d[4] in "15") else 4                  # cgemm_gauss.hip launch_cfg: CIK5 for the 5- and 1-row conv tiles
+        # cgemm_gauss.hip launch_cfg: 2 channels per K chunk for the one-workgroup 5- and 1-row conv tiles, 4 elsewhere
+        cik = 2 if (d[1] == "0" and d[4] in "15" and occ == 1) else 4
         jt = 32 * int(d[5]) * int(d[3])
         fr = 2 * int(d[4]) + 3 if d[1] == "0" else int(d[4]) + 2
         nbuf = 3 if 3 * cik * 3 * fr * (jt + 8) * 4 * occ <= 156 * 1024 else 2
