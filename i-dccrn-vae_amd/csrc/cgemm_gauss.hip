@@ -473,6 +473,10 @@ inline int occ2_max_cin() {
     static const int v = [] { const char* e = getenv("IDV_GAUSS_OCC2_MAXC"); return e ? atoi(e) : 128; }();
     return v;
 }
+inline bool tconv_wm4() {
+    static const bool v = [] { const char* e = getenv("IDV_GAUSS_TWM"); return !(e && atoi(e) == 2); }();
+    return v;
+}
 inline bool conv_cik2() {
     static const bool v = [] { const char* e = getenv("IDV_GAUSS_CCIK"); return e && atoi(e) == 2; }();
     return v;
@@ -487,6 +491,9 @@ int gauss_config(int transposed, int Cin, int Cout, int rows) {
     const int wide = Cout > 32;                       // two co tiles per workgroup where the layer has them
     if (transposed) {
         const bool occ2 = Cin <= occ2_max_cin();
+        // four co tiles x ONE column group per workgroup where the layer has four co tiles (a 72-column patch instead of 136
+        // per workgroup: dec0 13.63 -> 13.16 ms, dec1 12.61 -> 11.81, dec2 11.96 -> 11.52 at B = 64; IDV_GAUSS_TWM=2 restores 2 x 2)
+        if (!occ2 && Cout >= 128 && tconv_wm4()) return 3141121;
         return wide ? (occ2 ? 3122112 : 3122121) : (occ2 ? 3114112 : 3114121);
     }
     if (Cin <= conv_occ2_max_cin()) return wide ? 3022122 : 3014122;
@@ -508,6 +515,7 @@ int launch_cfg(const GaussArgs& a, int transposed, hipStream_t st) {
     }
     switch (gauss_config(transposed, a.C0 + a.C1, a.Cout, rows)) {
         // (eight channels per K chunk -- half the barriers -- change nothing here: three patch buffers already hide them)
+        case 3141121: return launch_gauss<IDV_TCONV, 4, 1, 1, 2, CIK, STATS>(a, st);
         case 3122121: return launch_gauss<IDV_TCONV, 2, 2, 1, 2, CIK, STATS>(a, st);
         case 3122112: return launch_gauss<IDV_TCONV, 2, 2, 1, 1, CIK, STATS, 2>(a, st);
         case 3114121: return launch_gauss<IDV_TCONV, 1, 4, 1, 2, CIK, STATS>(a, st);
