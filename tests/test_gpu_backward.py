@@ -946,7 +946,7 @@ def _full_width(pm, nl):
 # (encoders.2.bn.beta_r 5.4e-3 vs 4.7e-4), largest tensor under the floor 4.1e-3, whole vector 1.9e-3 vs 3.3e-4 (5.9x).
 # The float32 oracle has no flipped element in decoders 2-5 on this input (1e-6 there): that is what the floor is for.
 # How sharp the per-tensor ratio can be: the conv kernels' outputs and data gradients are BIT-identical across their tile
-# configurations (scratch/cfg_compare.py), only the train-mode moment sums differ -- by 1e-9, from the grouping of the fp32
+# configurations (tests/tools/conv_cfg_compare.py), only the train-mode moment sums differ -- by 1e-9, from the grouping of the fp32
 # per-wave partials -- and that alone moved encoders.5 (conv_im.weight, bn.gamma_ri, bn.beta_i) from under 3.3x to 5.0 / 10.1 /
 # 7.5x the float32 oracle's deviation (3.7e-3 .. 6.4e-3 against 6.4e-4 .. 7.6e-4) when the conv tiles changed late in round 3,
 # the whole vector from 5.2e-4 to 7.6e-4 (2.3x): one flipped PReLU element in front of the deepest encoder block.  The
