@@ -337,7 +337,7 @@ def kernel_name(cfg_id):
         d = str(cfg_id)
         occ = int(d[6])
         # cgemm_gauss.hip launch_cfg: 2 channels per K chunk for the one-workgroup 5- and 1-row conv tiles, 4 elsewhere
-        cik = 2 if (d[1] == "0" and d[4] in "15" and occ == 1) else 4
+        cik = 2 if (d[1] == "0" and d[4] in "15" and (occ == 1 or d[2:4] == "14")) else 4
         jt = 32 * int(d[5]) * int(d[3])
         fr = 2 * int(d[4]) + 3 if d[1] == "0" else int(d[4]) + 2
         nbuf = 3 if 3 * cik * 3 * fr * (jt + 8) * 4 * occ <= 156 * 1024 else 2

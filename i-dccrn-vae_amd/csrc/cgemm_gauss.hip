@@ -427,6 +427,7 @@ int launch_gauss_v(const GaussArgs& a, hipStream_t st) {
     constexpr int NE = CIK * 3 * G::FR * (JT + 8);
     constexpr int NBUF = (3 * NE * sizeof(float) * OCC <= 156 * 1024) ? 3 : 2;     // three patch buffers where the LDS holds them
     constexpr size_t smem = NBUF * NE * sizeof(float);
+    static_assert(smem * OCC <= 160 * 1024, "the patch buffers of OCC workgroups must fit the 160 KB of LDS");
     const int rows = (MODE == IDV_TCONV) ? a.Fin : a.Fout;
     GaussArgs b = a;
     b.jtiles = (a.J + JT - 1) / JT;
@@ -524,8 +525,8 @@ int launch_cfg(const GaussArgs& a, int transposed, hipStream_t st) {
         //  IDV_GAUSS_CCIK=2 restores the latter)
         case 3022122: return conv_cik2() ? launch_gauss<IDV_CONV, 2, 2, 1, 2, CIK5, STATS, 2>(a, st)
                                          : launch_gauss<IDV_CONV, 2, 2, 1, 2, CIK, STATS, 2>(a, st);
-        case 3014122: return conv_cik2() ? launch_gauss<IDV_CONV, 1, 4, 1, 2, CIK5, STATS, 2>(a, st)
-                                         : launch_gauss<IDV_CONV, 1, 4, 1, 2, CIK, STATS, 2>(a, st);
+        // (one co tile x four column groups: a 264-column patch -- four channels per chunk would not leave room for two workgroups)
+        case 3014122: return launch_gauss<IDV_CONV, 1, 4, 1, 2, CIK5, STATS, 2>(a, st);
         case 3022511: return launch_gauss<IDV_CONV, 2, 2, 5, 1, CIK5, STATS>(a, st);
         case 3022311: return launch_gauss<IDV_CONV, 2, 2, 3, 1, CIK, STATS>(a, st);
         case 3022141: return launch_gauss<IDV_CONV, 2, 2, 1, 4, CIK5, STATS>(a, st);
