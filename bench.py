@@ -150,7 +150,10 @@ def build_workload(name, B, device, rank):
         """zero_grad -> forward + loss -> backward -> [gradient all-reduce] -> Adam.step (lr 1e-3, weight_decay 1e-3:
         supervised_dccrn/train.py:109)."""
         params = [p_ for m in models for p_ in m.parameters() if p_.requires_grad]
-        opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-3)
+        # torch.optim.Adam semantics, one multi-tensor HIP launch per step (optim.py / csrc/bucket.hip); IDV_TORCH_ADAM=1: stock
+        hip_adam = os.environ.get("IDV_TORCH_ADAM", "0") != "1"
+        optim = importlib.import_module("i-dccrn-vae_amd.optim")
+        opt = (optim.Adam if hip_adam else torch.optim.Adam)(params, lr=1e-3, weight_decay=1e-3)
         red = par.GradAllReduce(params) if world > 1 else None
         if world > 1:
             par.enable_sync_bn()
@@ -160,9 +163,13 @@ def build_workload(name, B, device, rank):
                 opt.zero_grad(set_to_none=True)
                 loss = fwd_loss()
                 loss.backward()
-            if red is not None:
-                red.reduce()
-            opt.step()
+            if red is not None and hip_adam and len(red.buckets) == 1:
+                red.reduce(into_grads=False)              # gather -> RCCL all-reduce; Adam reads the averaged bucket
+                opt.step(grad_bucket=red.bucket())
+            else:
+                if red is not None:
+                    red.reduce()
+                opt.step()
             return loss.detach()
         return step
 

@@ -30,6 +30,35 @@ def declared_symbols() -> list:
     return sorted(set(re.findall(r"\b(idv_[a-z0-9_]+)\s*\(", src)))
 
 
+_CTYPES = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float, "double": ctypes.c_double}
+
+
+def prototypes() -> dict:
+    """name -> (return C type, [parameter C types]) of every function declared in include/idccrn_hip.h; a pointer of any
+    kind is the string "ptr"."""
+    with open(HEADER_PATH) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//.*", "", src)
+    out = {}
+    for ret, name, args in re.findall(r"\b(int|long long|void)\s+(idv_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+        params = []
+        for a in args.split(","):
+            a = a.strip()
+            if not a or a == "void":
+                continue
+            t = re.sub(r"\b[a-zA-Z_][a-zA-Z0-9_]*$", "", a).strip()
+            if t.endswith("*"):
+                params.append("ptr")
+            else:
+                t = t.replace("const ", "").strip()
+                if t not in _CTYPES:
+                    raise IdvError(f"include/idccrn_hip.h: unknown parameter type {t!r} in {name}")
+                params.append(t)
+        out[name] = (ret, params)
+    return out
+
+
 def declared_abi_version() -> int:
     with open(HEADER_PATH) as f:
         m = re.search(r"#define\s+IDV_ABI_VERSION\s+(\d+)", f.read())
@@ -52,13 +81,19 @@ def lib() -> ctypes.CDLL:
             _lib = None
             raise IdvError(f"{LIB_PATH} has ABI version {got}, include/idccrn_hip.h declares {want}: rebuild it "
                            "(`python __graft_entry__.py`)")
+        protos = prototypes()
         for name in declared_symbols():
             if not hasattr(_lib, name):
                 if os.environ.get("IDV_DEV_PARTIAL_LIB"):
                     continue
                 raise IdvError(f"libidccrn_hip.so does not export {name}")
-            if name == "idv_clstm_work_floats":
-                _lib.idv_clstm_work_floats.restype = ctypes.c_longlong
+            if name in protos:
+                # the header's prototypes become ctypes signatures: a `long long` / `double` argument can then not be
+                # truncated by a call site that forgot its ll() / d() wrapper, and a wrong argument count raises
+                ret, params = protos[name]
+                fn = getattr(_lib, name)
+                fn.argtypes = [ctypes.c_void_p if t == "ptr" else _CTYPES[t] for t in params]
+                fn.restype = None if ret == "void" else _CTYPES[ret]
     return _lib
 
 
@@ -73,7 +108,8 @@ def call(name: str, *args):
     """Call an idv_* entry; tensors become device pointers, python numbers keep their C type
     via the wrappers p()/i()/f()/d()/ll().  Raises IdvError on a non-zero status."""
     fn = getattr(lib(), name)
-    rc = fn(*args)
+    # wrapped scalars go in by VALUE: the prototype (argtypes) decides the C type, so i(n) for a `long long` parameter widens
+    rc = fn(*[a.value if isinstance(a, (_I, _L, _F, _D)) else a for a in args])
     if rc != 0:
         what = {-1: "invalid argument", -2: "launch failure",
                 -3: "an earlier cooperative recurrence timed out (a sibling workgroup never became resident); its outputs "

@@ -57,16 +57,34 @@ def invalidate_caches(module: nn.Module):
                 v.key = None
 
 
+def _tensors_of(v):
+    if isinstance(v, torch.Tensor):
+        yield v
+    elif isinstance(v, (tuple, list)):
+        for u in v:
+            yield from _tensors_of(u)
+
+
 class _PackCache:
-    """Re-pack weights only when a parameter changed (tensor._version / storage) or the fold did."""
+    """Re-pack weights only when a parameter changed (tensor._version / storage) or the fold did.
+
+    Cross-stream ownership (sub-batch streams of DCCRN_.forward, ops.concurrent) is explicit:
+    * the pack kernels run on the stream that found the key changed; `ready` is recorded there and EVERY other stream waits
+      on it on the device before its first use of this value (one wait per stream, remembered in `waited`; the event is
+      kept for the life of the value, a completed event costs nothing to wait on);
+    * every stream that reads the value is told to the caching allocator (`record_stream`), so that when the value is
+      replaced its memory is not handed out again before the work those streams had queued on it has finished."""
 
     def __init__(self):
         self.key = None
         self.val = None
         self.ready = None
+        self.owner = None            # stream (handle) the value was packed on
+        self.waited = set()          # streams that are ordered behind `ready`, and known to the allocator as users
 
     def get(self, tensors, extra, build):
         key = tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (extra,)
+        cur = torch.cuda.current_stream()
         if key != self.key:
             for t in tensors:
                 # the pack kernels dereference raw pointers: parameters left on the CPU (module built but never moved) must
@@ -74,17 +92,17 @@ class _PackCache:
                 if t is not None and not t.is_cuda:
                     raise RuntimeError("i-dccrn-vae_amd: a parameter of this module is on the CPU; move the module to the GPU "
                                        "(module.cuda()) -- the HIP hot path has no CPU fallback")
-            self.val = build()
+            self.val = build()       # the old value's blocks go back to the allocator, which holds them for recorded users
             self.key = key
-            # the pack kernels ran on the current stream; later users may be on another one (sub-batch streams):
-            # they wait on this event on the device, the host never blocks
             self.ready = torch.cuda.Event()
-            self.ready.record()
-        elif self.ready is not None:
-            if self.ready.query():
-                self.ready = None                       # packed long ago: nothing to order any more
-            else:
-                torch.cuda.current_stream().wait_event(self.ready)
+            self.ready.record(cur)
+            self.owner = cur.cuda_stream
+            self.waited = {self.owner}
+        elif cur.cuda_stream not in self.waited:
+            cur.wait_event(self.ready)
+            for t in _tensors_of(self.val):
+                t.record_stream(cur)
+            self.waited.add(cur.cuda_stream)
         return self.val
 
 

@@ -372,6 +372,7 @@ class DCCRN_(nn.Module):
         encoded = None                                            # staggered: part k+1 starts when part k enters its LSTM
         for part, st in zip(signal.tensor_split(n), streams):
             st.wait_event(ready)
+            part.record_stream(st)                                # the input is read on st: its block is not re-used before st is done
             if encoded is not None and ops.STREAM_STAGGER and part.shape[0] < ops.STREAM_STAGGER_BELOW:
                 st.wait_event(encoded)
             encoded = torch.cuda.Event()
@@ -379,9 +380,11 @@ class DCCRN_(nn.Module):
                 outs.append(self._forward_one(part, False, encoded.record) + (self.std_DCCRN.latent,))
         for st in streams:                                        # join only after every part is enqueued
             main.wait_stream(st)
+        # Explicit cross-stream ownership: every part's outputs were allocated from their side stream's pool
+        # and are read by the concatenations on `main`; record_stream makes the allocator keep those blocks until main has
+        # passed the point where they are released, whatever the side stream does next.
+        ops.hand_over(outs, main)
         clean, predict, latent = (torch.cat([o[k] for o in outs]) for k in range(3))
-        # no record_stream: the parts are released to their own stream's pool, and that stream's next use starts
-        # with wait_event(ready) above, i.e. after these concatenations have run
         self.std_DCCRN.latent = latent
         return clean, predict
 

@@ -403,7 +403,26 @@ def concurrent(fns, device=None):
             outs.append(fn())
     for st in streams:
         main.wait_stream(st)
+    hand_over(outs, main)
     return outs
+
+
+def hand_over(obj, stream):
+    """Tell the caching allocator that `stream` reads every tensor reachable from `obj` (nested tuples / lists, the planar
+    buffer a reference-shaped view carries as `_idv`): blocks that came from another stream's pool are then not handed
+    out again before `stream` has passed the point where they are released.  Explicit cross-stream ownership instead of an
+    argument about what the other stream does next."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+        pl = getattr(obj, "_idv", None)
+        if pl is not None and isinstance(getattr(pl, "buf", None), torch.Tensor) and pl.buf.is_cuda:
+            pl.buf.record_stream(stream)
+    elif isinstance(obj, (Planar, Image)):
+        obj.buf.record_stream(stream)
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            hand_over(o, stream)
 
 
 # Train-mode moment sums: the conv epilogues spread their atomic adds over this many replicas of the [Cout][5] sums
@@ -879,6 +898,7 @@ def zero_bias(cout: int, device):
     key = (mtiles_alloc(2 * cout), str(device))
     if key not in _ZBIAS:
         _ZBIAS[key] = torch.zeros(key[0] * 32, dtype=torch.float32, device=device)
+        torch.cuda.current_stream(device).synchronize()       # filled once; later users may sit on other streams
     return _ZBIAS[key]
 
 

@@ -16,6 +16,7 @@ device tensors are staged through host memory.
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -24,13 +25,26 @@ import torch.distributed as dist
 from . import ops
 
 
+# Test hook (tests/test_gpu_rccl.py): with a process group of ONE rank the collectives are still issued instead of being
+# skipped, so that the RCCL branch of every function below executes on a one-GPU box (a sum / average over one rank is the
+# identity, the step's results must not change).
+FORCE_COLLECTIVES = os.environ.get("IDV_DP_FORCE", "0") == "1"
+
+
 def _world(group=None) -> int:
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def _active(group=None) -> bool:
+    """Are collectives issued?  More than one rank -- or an initialised group of one with FORCE_COLLECTIVES."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
+
+
 def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM all-reduce; gloo cannot take device tensors on every build, so they go through the host there."""
-    if _world(group) == 1:
+    if not _active(group):
         return t
     if t.is_cuda and dist.get_backend(group) != "nccl":
         h = t.detach().cpu()
@@ -48,7 +62,7 @@ def sync_moments(sums: torch.Tensor, group=None) -> int:
 
 
 def enable_sync_bn(group=None):
-    ops.BN_SYNC = (lambda sums: sync_moments(sums, group)) if _world(group) > 1 else None
+    ops.BN_SYNC = (lambda sums: sync_moments(sums, group)) if _active(group) else None
 
 
 def disable_sync_bn():
@@ -56,31 +70,74 @@ def disable_sync_bn():
 
 
 class GradAllReduce:
-    """Bucketed gradient averaging for the parameters that require grad."""
+    """Bucketed gradient averaging for the parameters that require grad.
+
+    Device parameters: per bucket ONE multi-tensor gather kernel (``idv_bucket_gather``: every ``.grad`` -> the flat bucket,
+    absent gradients as zeros), the RCCL all-reduce (``ReduceOp.AVG``), and ONE scatter kernel back into the ``.grad``
+    tensors -- or none at all: ``reduce(into_grads=False)`` leaves the averaged gradients in the bucket and
+    ``optim.Adam.step(grad_bucket=red.bucket())`` reads them there.  Buckets are filled from the LAST registered parameters
+    to the first (the order backward produces gradients in); inside a bucket the parameters keep registration order, so
+    the one-bucket case (every shipped model: <= 100 MB against the 128 MB default) has the optimiser's own layout.
+    CPU parameters (the gloo protocol test) take a plain torch loop."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 128 << 20, group=None):
         self.group = group
         ps = [p for p in params if p.requires_grad]
-        ps.reverse()                                     # backward produces the last layers' gradients first
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, size = [], 0
-        for p in ps:
+        for p in reversed(ps):
             n = p.numel() * p.element_size()
             if cur and size + n > bucket_bytes:
-                self.buckets.append(cur)
+                self.buckets.append(cur[::-1])
                 cur, size = [], 0
             cur.append(p)
             size += n
         if cur:
-            self.buckets.append(cur)
+            self.buckets.append(cur[::-1])
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._tab = [None] * len(self.buckets)
+        self._present = [None] * len(self.buckets)
+        self._scale = 1.0
 
-    def reduce(self):
+    def bucket(self, bi: int = 0):
+        """(layout, flat buffer, scale, present) of bucket `bi` after ``reduce(into_grads=False)``: what ``optim.Adam.step``
+        takes; present[k] = parameter k had a gradient on this rank (the reference's optimiser skips the others -- e.g. the
+        constructed-but-unused ``linear`` conv of standard_DCCRN, pvae_module.py:158 -- and so does the kernel)."""
+        return self._tab[bi], self._flat[bi], self._scale, self._present[bi]
+
+    def _reduce_device(self, bi: int, bucket, world: int, into_grads: bool):
+        from . import optim
+        tab = self._tab[bi]
+        if tab is None:
+            tab = self._tab[bi] = optim.TensorTable([p.numel() for p in bucket], bucket[0].device)
+            self._flat[bi] = tab.flat()
+        flat = self._flat[bi]
+        grads = [None if p.grad is None else (p.grad if p.grad.is_contiguous() else p.grad.contiguous()) for p in bucket]
+        self._present[bi] = [g is not None for g in grads]
+        optim.bucket_gather(tab, grads, flat)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)        # RCCL, on the device buffer
+            self._scale = 1.0
+        else:
+            all_reduce_sum_(flat, self.group)
+            self._scale = 1.0 / world
+        if into_grads:
+            for p in bucket:
+                if p.grad is None:
+                    p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
+                elif not p.grad.is_contiguous():
+                    p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
+            optim.bucket_scatter(tab, [p.grad for p in bucket], flat, self._scale)
+
+    def reduce(self, into_grads: bool = True):
         """Average ``.grad`` over the ranks (parameters without a gradient on this rank contribute zeros)."""
         world = _world(self.group)
-        if world == 1:
+        if not _active(self.group):
             return
         for bi, bucket in enumerate(self.buckets):
+            if bucket[0].is_cuda:
+                self._reduce_device(bi, bucket, world, into_grads)
+                continue
             n = sum(p.numel() for p in bucket)
             flat = self._flat[bi]
             if flat is None or flat.numel() != n or flat.device != bucket[0].device:
@@ -93,11 +150,8 @@ class GradAllReduce:
                 else:
                     flat[o:o + k].copy_(p.grad.reshape(-1))
                 o += k
-            if flat.is_cuda and dist.get_backend(self.group) == "nccl":
-                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-            else:
-                all_reduce_sum_(flat, self.group)
-                flat.div_(world)
+            all_reduce_sum_(flat, self.group)
+            flat.div_(world)
             o = 0
             for p in bucket:
                 k = p.numel()

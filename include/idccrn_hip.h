@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IDV_ABI_VERSION 5
+#define IDV_ABI_VERSION 6
 #define IDV_SLACK_FLOATS 256
 
 int idv_abi_version(void);
@@ -555,6 +555,27 @@ int idv_lstm_bptt_coop(float* gates, long long g_run_z, long long g_run_s, int l
                        const float* whhT, int H, int B, int T, void* work, void* stream);
 int idv_rows_to_planar(const float* src, long long ld, int c0, int ncol, int B, int T, int Tp, int Jp, float* dst, void* stream);
 int idv_lstm_bias_grad(const float* dGp, int H, int Jp, int J, int accumulate, float* db, void* stream);
+
+/* ---- data-parallel train step: gradient bucket and optimiser as multi-tensor kernels (bucket.hip) --------------------------
+ * The reference trains on one device with stock torch (`loss.backward(); optimizer.step()` with
+ * torch.optim.Adam(lr, weight_decay=0.001): supervised_dccrn/train.py:109, 239-243; i_dccrn_vae/nsvae_dccrn/train_nsvae.py:200,
+ * 557-561; i_dccrn_vae/nsvae_dccrn/train_second_phase_decoder.py:420-433; i_dccrn_vae/pretrained_vaes/train.py:296-301).
+ * Bucket layout: a flat fp32 buffer in which tensor i occupies [off_i, off_i + numel_i), every off_i a multiple of 4 floats,
+ * the gaps zero padding; table[n][3] (int64, device memory, sorted by off) = {device pointer of the tensor's first element
+ * (0: absent), off_i, numel_i}; total = the padded length (multiple of 4); flat is 16-byte aligned.
+ *   idv_bucket_gather : flat <- tensors (absent tensors and padding as zeros): the operand of the RCCL all-reduce;
+ *   idv_bucket_scatter: tensors <- scale * flat (scale 1 after ReduceOp.AVG, 1 / world after a SUM);
+ *   idv_bucket_adam   : one torch.optim.Adam step (no amsgrad / maximize) over all tensors of the table: parameters through
+ *     ptable, gradients EITHER through gtable (same offsets) OR straight from a bucket gflat (e.g. the all-reduced one, so the
+ *     scatter pass disappears), multiplied by grad_scale; exp_avg / exp_avg_sq in the bucket layout;
+ *     bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t) for the step count t of this step; the betas are
+ *     doubles because torch forms 1 - beta in double before rounding (1 - 0.999f in float is 1.3e-5 off).  A table row with a
+ *     NULL parameter pointer is skipped (a parameter that received no gradient keeps its value and moments, as in torch). */
+int idv_bucket_gather(const long long* table, int n, long long total, float* flat, void* stream);
+int idv_bucket_scatter(const long long* table, int n, long long total, const float* flat, float scale, void* stream);
+int idv_bucket_adam(const long long* ptable, const long long* gtable, const float* gflat, float* exp_avg, float* exp_avg_sq,
+                    int n, long long total, float lr, double beta1, double beta2, float eps, float weight_decay,
+                    float bias_correction1, float bias_correction2_sqrt, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

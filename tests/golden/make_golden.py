@@ -387,7 +387,10 @@ def gen_grad_dccrn(tag, base, B, L, seed, weights, limit=16384, cap=8192, adam=T
     save(f"grad_dccrn_{tag}", **out)
 
 
-def gen_grad_vae(tag, base, zdim, B, L, ns, seed):
+def gen_grad_vae(tag, base, zdim, B, L, ns, seed, limit=16384, cap=8192, adam=True):
+    """The three VAE train steps against the reference's own loss.backward().  tag "mini": reduced width, every gradient element
+    (up to `limit`) + one Adam step; tag "full": the reference's full width (base 32, zdim 128 -> LSTM hidden 384 / 768, K = 1280
+    projections, repeated-skip decoder), gradients subsampled to `cap` elements per tensor + full L2 norms."""
     print(f"== grads VAE {tag}: base={base} zdim={zdim} B={B} L={L} ns={ns}")
     np_ = O.net_params(True, base)
     skip = [0, 1, 2, 3, 4, 5]
@@ -417,10 +420,12 @@ def gen_grad_vae(tag, base, zdim, B, L, ns, seed):
         lo[0].backward()
     out = dict(x=x, eps_r=eps[0], eps_i=eps[1], seed=seed, base=base, zdim=zdim, ns=ns, weights=np.asarray(w, dtype="float32"),
                loss=torch.stack([torch.as_tensor(v).detach().float() for v in (lo[0], lo[1], lo[2], lo[4], lo[5], lo[6])]))
-    grad_record(out, "enc.", enc)
-    grad_record(out, "dec.", dec)
-    with torch.no_grad():
-        adam_record(out, "enc.", enc), adam_record(out, "dec.", dec)
+    out.update(sum_limit=limit, sum_cap=cap)
+    grad_record(out, "enc.", enc, limit, cap)
+    grad_record(out, "dec.", dec, limit, cap)
+    if adam:
+        with torch.no_grad():
+            adam_record(out, "enc.", enc), adam_record(out, "dec.", dec)
     save(f"grad_cvae_{tag}", **out)
 
     # ---- NSVAE step (train_nsvae.py:487-574): frozen clean / noise encoders (eval, no_grad), noisy encoder trains
@@ -451,9 +456,11 @@ def gen_grad_vae(tag, base, zdim, B, L, ns, seed):
     out = dict(clean=clean, noise=noise, seed=seed, base=base, zdim=zdim, ns=ns,
                **{f"eps{i}": e for i, e in enumerate(epsn)},
                loss=torch.stack([torch.as_tensor(v).detach().float() for v in ln_out[:6]]))
-    grad_record(out, "noisy.", ye)
-    with torch.no_grad():
-        adam_record(out, "noisy.", ye)
+    out.update(sum_limit=limit, sum_cap=cap)
+    grad_record(out, "noisy.", ye, limit, cap)
+    if adam:
+        with torch.no_grad():
+            adam_record(out, "noisy.", ye)
     save(f"grad_nsvae_{tag}", **out)
 
     # ---- decoder fine-tune step (train_second_phase_decoder.py:376-433): frozen noisy encoder (eval), decoder trains
@@ -482,9 +489,11 @@ def gen_grad_vae(tag, base, zdim, B, L, ns, seed):
     out = dict(clean=clean, noise=noise, seed=seed, base=base, zdim=zdim, ns=ns,
                **{f"eps{i}": e for i, e in enumerate(eps2)},
                loss=torch.stack([torch.as_tensor(v).detach().float() for v in l2[:4]]), recon=rec.detach())
-    grad_record(out, "dec.", de2)
-    with torch.no_grad():
-        adam_record(out, "dec.", de2)
+    out.update(sum_limit=limit, sum_cap=cap)
+    grad_record(out, "dec.", de2, limit, cap)
+    if adam:
+        with torch.no_grad():
+            adam_record(out, "dec.", de2)
     save(f"grad_twophase_{tag}", **out)
 
 
@@ -819,6 +828,11 @@ if __name__ == "__main__":
         # elements per tensor + full L2 norms
         torch.set_num_threads(os.cpu_count())
         gen_grad_dccrn("full", 32, 2, 16000, 91, [0.2, 0.1, 1.0], limit=2048, cap=1024, adam=False)
+    if "gradvaefull" in which:
+        # the three VAE train steps (BASELINE configs 2-5) at the reference's FULL width: base 32, zdim 128 (LSTM hidden 384 for the
+        # CVAE encoder, 768 for the noisy encoder), 1 s utterances, B = 2, ns = 2
+        torch.set_num_threads(os.cpu_count())
+        gen_grad_vae("full", 32, 128, 2, 16000, 2, 93, limit=2048, cap=1024, adam=False)
     if "extras" in which or "datanorm" in which:
         gen_datanorm()
     if "extras" in which:

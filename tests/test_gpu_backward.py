@@ -615,9 +615,41 @@ def _dump(name, obj):
             json.dump(obj, f, indent=0, sort_keys=True)
 
 
-def test_grad_cvae_reference(pm, losses, golden):
+# The VAE train steps against the reference's own loss.backward(): "mini" = reduced width (every gradient element + one Adam
+# step); "full" = the reference's FULL width (base 32, zdim 128: LSTM hidden 384 / 768 on the persistent recurrences, per-step or
+# cooperative BPTT, the K = 1280 input projections with their data / weight gradients, the repeated-skip decoder at its real
+# channel counts), 1 s utterances, B = 2 x ns = 2, make_golden.py gradvaefull: 1024-element subsample + full L2 norm per tensor.
+VAE_GRAD_CASES = [("mini", "fp32"), ("full", "fp32"), ("full", "bf16x3")]
+# full width: a handful of PReLU pre-activations within rounding of zero take the other branch and move every upstream gradient
+# (test_full_width_train_step_grads); tolerances = those of the supervised full-width fixture, the measured values are printed
+VAE_GRAD_TOL = {("mini", "fp32"): (1e-3, None, 2e-4), ("full", "fp32"): (1e-2, 3e-2, 5e-4), ("full", "bf16x3"): (3e-2, 9e-2, 2e-3)}
+
+
+class _Precision:
+    def __init__(self, ops, mode):
+        self.ops, self.mode = ops, mode
+
+    def __enter__(self):
+        self.keep = self.ops.PRECISION
+        self.ops.set_precision(self.mode)
+
+    def __exit__(self, *a):
+        self.ops.set_precision(self.keep)
+
+
+def _vae_grad_report(name, tag, precision, errs):
+    e = sorted(errs.values())
+    if e:
+        print(f"{name}[{tag},{precision}]: {len(e)} tensors, median {e[len(e) // 2]:.2e}, 90th percentile {e[(9 * len(e)) // 10]:.2e}, "
+              f"max {e[-1]:.2e}")
+        _dump(f"grad_ref_{name}_{tag}_{precision}", errs)
+
+
+@pytest.mark.parametrize("tag,precision", VAE_GRAD_CASES)
+def test_grad_cvae_reference(pm, losses, golden, ops, tag, precision):
     """pretrained_vaes/train.py:281-301: encoder -> reparameterised z -> decoder (zero skips) -> ELBO -> backward."""
-    d = golden("grad_cvae_mini")
+    d = golden(f"grad_cvae_{tag}")
+    tol, tol1, ltol = VAE_GRAD_TOL[(tag, precision)]
     _, plm, _ = losses
     base, seed, zdim, ns = int(d["base"]), int(d["seed"]), int(d["zdim"]), int(d["ns"])
     np_ = O.net_params(True, base)
@@ -627,7 +659,7 @@ def test_grad_cvae_reference(pm, losses, golden):
     B, L = x.shape
     eps = (T_(d["eps_r"]).cuda(), T_(d["eps_i"]).cuda())
     w = [float(v) for v in d["weights"]]
-    with torch.enable_grad():
+    with torch.enable_grad(), _Precision(ops, precision):
         z, miu, ls, dl, skiper, C, F, stft_x = enc(x, train=True, eps=eps)
         recon, pred = dec(stft_x, z, skiper, C, F, train=True)
         xr = x.unsqueeze(1).repeat(1, ns, 1).view(B * ns, L)
@@ -637,15 +669,20 @@ def test_grad_cvae_reference(pm, losses, golden):
         lo[0].backward()
     got = torch.stack([torch.as_tensor(float(v)) for v in (lo[0], lo[1], lo[2], lo[4], lo[5], lo[6])])
     for a, b in zip(got, T_(d["loss"])):
-        assert abs(float(a) - float(b)) < 2e-4 * max(1.0, abs(float(b)))
-    print("worst", check_grads(d, "enc.", enc), check_grads(d, "dec.", dec))
-    check_adam(d, "enc.", enc)
-    check_adam(d, "dec.", dec)
+        assert abs(float(a) - float(b)) < ltol * max(1.0, abs(float(b))), (float(a), float(b))
+    errs = {}
+    print("worst", check_grads(d, "enc.", enc, tol, tol1, errs), check_grads(d, "dec.", dec, tol, tol1, errs))
+    _vae_grad_report("cvae", tag, precision, errs)
+    if tag == "mini":
+        check_adam(d, "enc.", enc)
+        check_adam(d, "dec.", dec)
 
 
-def test_grad_nsvae_reference(pm, losses, golden):
+@pytest.mark.parametrize("tag,precision", VAE_GRAD_CASES)
+def test_grad_nsvae_reference(pm, losses, golden, ops, tag, precision):
     """train_nsvae.py:487-574: frozen clean / noise encoders (eval, no_grad), trainable noisy encoder, nsvae KL loss."""
-    d = golden("grad_nsvae_mini")
+    d = golden(f"grad_nsvae_{tag}")
+    tol, tol1, ltol = VAE_GRAD_TOL[(tag, precision)]
     nl, _, _ = losses
     base, seed, zdim, ns = int(d["base"]), int(d["seed"]), int(d["zdim"]), int(d["ns"])
     np_ = O.net_params(True, base)
@@ -655,24 +692,30 @@ def test_grad_nsvae_reference(pm, losses, golden):
     clean, noise = T_(d["clean"]).cuda(), T_(d["noise"]).cuda()
     noisy = clean + noise
     e = [T_(d[f"eps{i}"]).cuda() for i in range(8)]
-    with torch.no_grad():
-        zc, mc, lc, dc, skc, _, _, _ = ce(clean, train=False, eps=(e[0], e[1]))
-        zn, mn, ln_, dn, skn, _, _, _ = ne(noise, train=False, eps=(e[2], e[3]))
-    with torch.enable_grad():
-        zs, ms, ls_, ds, znn, mnn, lnn, dnn, sky, C, F, stft_y = ye(noisy, train=True, eps=(e[4], e[5], e[6], e[7]))
-        L_ = nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.5, zdim, ns, 2, 'original', 'False', [], 'both')
-        out = L_.final_nsvae_loss(mc, mn, ms, mnn, lc, ln_, ls_, lnn, dc, dn, ds, dnn, zs, znn, skc, skn, sky)
-        out[0].backward()
+    with _Precision(ops, precision):
+        with torch.no_grad():
+            zc, mc, lc, dc, skc, _, _, _ = ce(clean, train=False, eps=(e[0], e[1]))
+            zn, mn, ln_, dn, skn, _, _, _ = ne(noise, train=False, eps=(e[2], e[3]))
+        with torch.enable_grad():
+            zs, ms, ls_, ds, znn, mnn, lnn, dnn, sky, C, F, stft_y = ye(noisy, train=True, eps=(e[4], e[5], e[6], e[7]))
+            L_ = nl.standard_nsvae_loss_true_kl(1.0, 0, 1.0, 0.5, zdim, ns, 2, 'original', 'False', [], 'both')
+            out = L_.final_nsvae_loss(mc, mn, ms, mnn, lc, ln_, ls_, lnn, dc, dn, ds, dnn, zs, znn, skc, skn, sky)
+            out[0].backward()
     for a, b in zip(out[:6], T_(d["loss"])):
-        assert abs(float(a) - float(b)) < 3e-4 * max(1.0, abs(float(b)))
-    print("worst", check_grads(d, "noisy.", ye))
-    check_adam(d, "noisy.", ye)
+        assert abs(float(a) - float(b)) < 1.5 * ltol * max(1.0, abs(float(b))), (float(a), float(b))
+    errs = {}
+    print("worst", check_grads(d, "noisy.", ye, tol, tol1, errs))
+    _vae_grad_report("nsvae", tag, precision, errs)
+    if tag == "mini":
+        check_adam(d, "noisy.", ye)
     assert all(p_.grad is None for p_ in ce.parameters())
 
 
-def test_grad_twophase_reference(pm, losses, golden):
+@pytest.mark.parametrize("tag,precision", VAE_GRAD_CASES)
+def test_grad_twophase_reference(pm, losses, golden, ops, tag, precision):
     """train_second_phase_decoder.py:376-433: frozen noisy encoder (eval), decoder with repeated real skips, SI-SNR."""
-    d = golden("grad_twophase_mini")
+    d = golden(f"grad_twophase_{tag}")
+    tol, tol1, ltol = VAE_GRAD_TOL[(tag, precision)]
     nl, _, _ = losses
     base, seed, zdim, ns = int(d["base"]), int(d["seed"]), int(d["zdim"]), int(d["ns"])
     np_ = O.net_params(True, base)
@@ -685,7 +728,7 @@ def test_grad_twophase_reference(pm, losses, golden):
     noisy = clean + noise
     B, L = clean.shape
     e = [T_(d[f"eps{i}"]).cuda() for i in range(4)]
-    with torch.enable_grad():
+    with torch.enable_grad(), _Precision(ops, precision):
         r = ye(noisy, train=False, eps=tuple(e))
         zs, sky, C, F, stft_y = r[0], r[8], r[9], r[10], r[11]
         rec, prd = de(stft_y, zs, sky, C, F, train=True, pad='sig')
@@ -694,11 +737,16 @@ def test_grad_twophase_reference(pm, losses, golden):
         tl = nl.two_phase_loss([0, 0, 1], 1.0, zdim, 1)
         l2 = tl.phase_2_loss(prd, sxc, cb, rec, None, None, None, None)
         l2[0].backward()
-    assert relerr(rec.detach().cpu(), T_(d["recon"])) < 1e-4
+    rerr = relerr(rec.detach().cpu(), T_(d["recon"]))
+    print(f"twophase[{tag},{precision}] waveform rel err {rerr:.2e}")
+    assert rerr < (1e-4 if precision == "fp32" else 1e-3)
     for a, b in zip(l2[:4], T_(d["loss"])):
-        assert abs(float(a) - float(b)) < 2e-4 * max(1.0, abs(float(b)))
-    print("worst", check_grads(d, "dec.", de))
-    check_adam(d, "dec.", de)
+        assert abs(float(a) - float(b)) < ltol * max(1.0, abs(float(b))), (float(a), float(b))
+    errs = {}
+    print("worst", check_grads(d, "dec.", de, tol, tol1, errs))
+    _vae_grad_report("twophase", tag, precision, errs)
+    if tag == "mini":
+        check_adam(d, "dec.", de)
 
 
 def test_eval_after_train_uses_updated_running_stats(pm, ops):

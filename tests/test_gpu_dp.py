@@ -38,7 +38,7 @@ def _train_step(rank, world):
     np_ = O.net_params(True, 4)
     m = pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None)
     m.load_state_dict(O.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 17))
-    m = _smooth(m).cuda()
+    m = _offkink(m).cuda()
     g = torch.Generator().manual_seed(4)
     noisy = torch.randn(4, 1600, generator=g) * 0.1
     clean = noisy + torch.randn(4, 1600, generator=g) * 0.05
@@ -63,25 +63,37 @@ ZDIM, NS, BG, LG = 16, 2, 4, 1600         # zdim 16 -> LSTM hidden 48 (CVAE / NV
 
 def _load(module, seed):
     module.load_state_dict(O.synth_state_dict({k: tuple(v.shape) for k, v in module.state_dict().items()}, seed))
-    return _smooth(module).cuda()
+    return _offkink(module, ZDIM if hasattr(module, "zdim") and hasattr(module, "lstms") else None).cuda()
 
 
-def _smooth(module):
-    """PReLU slope 1 for the strict comparison.  The two-rank and the one-rank run differ by fp32 rounding of the all-reduced
-    batch statistics (1e-7), hence by ~4e-6 in every pre-activation; with the synthetic slope of 0.25 a pre-activation that
-    lies within that distance of zero takes the other branch in one of the runs and changes every upstream gradient by 1e-3
-    (measured: one such element among the 37 000 of decoders.1 with the three-product conv kernel's rounding, none with
-    cgemm_kernel's -- tests/tools/dp_probe.py).  That is the kink of PReLU, not the data-parallel machinery this test is about:
-    with slope 1 the activation path (kernel branches, dslope sums) still runs, and 1e-5 holds whatever the rounding."""
-    if SMOOTH:
-        with torch.no_grad():
-            for k, p_ in module.named_parameters():
-                if k.endswith("prelu.weight"):
-                    p_.fill_(1.0)
+def _offkink(module, zdim=None):
+    """Move the synthetic model OFF its two non-smooth points, so that a strict comparison can keep the real PReLU slope
+    (0.25: negative branch and a dslope that is not the identity) and the real reparameterisation guard.
+
+    The two-rank and the one-rank run differ by fp32 rounding of per-tile partial moment sums (1e-7), i.e. by ~4e-6 in every
+    pre-activation.  (a) PReLU kink: with pre-activations of unit scale around zero, a model of ~2e5 activations has about one
+    element within that distance of zero, and one element taking the other branch moves every upstream gradient by 1e-3
+    (tests/tools/dp_probe.py).  The batch-norm shifts beta_r / beta_i are therefore set to +-9 (sign alternating per channel,
+    re and im out of phase): every pre-activation is >= 7 sigma away from zero, half of the channels on each branch.
+    (b) Reparameterisation guard (|delta| >= sigma - 1e-3 -> delta rescaled to 0.99 sigma, pvae_module.py:1845-1852), a jump:
+    the cell-input gate rows of the LSTM's last layer that produce the delta units are scaled by 1e-2, so |delta| <~ 0.02
+    while sigma = exp(log_sigma) >= 0.13."""
+    with torch.no_grad():
+        for k, p_ in module.named_parameters():
+            if k.endswith("bn.beta_r") or k.endswith("bn.beta_i"):
+                sign = torch.ones_like(p_)
+                sign[(1 if k.endswith("beta_i") else 0)::2] = -1.0
+                sign[3::4] *= -1.0
+                p_.copy_(9.0 * sign)
+        if zdim is not None:
+            for lstm in module.lstms:
+                H = lstm.hidden_size
+                for run in (lstm.lstm_re, lstm.lstm_im):
+                    for name in ("weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1"):
+                        w = getattr(run, name)
+                        for k0 in range(0, H, 3 * zdim):                       # one (miu | log_sigma | delta) triple per latent
+                            w[2 * H + k0 + 2 * zdim:2 * H + k0 + 3 * zdim] *= 1e-2     # gate order i, f, g, o: rows of g
     return module
-
-
-SMOOTH = True
 
 
 def _vae_inputs(par, rank, world, n_eps):
@@ -175,12 +187,27 @@ def _twophase_step(rank, world):
 # the nsvae KL loss is a difference of O(zdim) terms (trace + quadratic + log-determinants - zdim): fp32 rounding of the all-reduced
 # batch statistics shows up 100x amplified in it
 LOSS_TOL = {"dccrn": 1e-5, "nsvae": 2e-4, "twophase": 1e-5}
-# ... and the reparameterisation guard (|delta| >= sigma - 1e-3 -> delta rescaled to 0.99 sigma, pvae_module.py:1845-1852) is a
-# JUMP: with synthetic weights a sizeable share of the latent elements sits near that boundary, and the 1e-7 difference between
-# the two runs moves some of them across it (the forward loss already differs by 3e-5).  The nsvae gradients are therefore held
-# to 3e-2 -- every structural error of the data-parallel step (a missing moment all-reduce, a missing 1 / world) is >= 10 % --
-# while the running batch-norm buffers, which the guard does not touch, stay at 1e-5.
-GRAD_TOL = {"dccrn": 1e-5, "nsvae": 3e-2, "twophase": 1e-5}
+# With the model off the PReLU kink and off the reparameterisation guard's jump (_offkink) every train step is a smooth function
+# of the batch statistics, and the two runs agree to rounding: 1e-5 (supervised, decoder fine-tune) and 1e-4 (NSVAE: its KL loss
+# amplifies the statistics' rounding 100x, LOSS_TOL) on every checked tensor but two kinds, which are sums with heavy cancellation
+# and carry the rounding of their large terms -- measured, round 4:
+#   * a PReLU slope's gradient: sum over the negative-branch channels of dz * u with u = -9 +- 1 by construction, while sum(dz) of a
+#     channel is ~0 because a batch norm follows (2.6e-5 on encoders.5.prelu.weight) -> 1e-4;
+#   * the first conv's weight in the NSVAE step, the end of the longest backward chain through six batch-norm backwards (2.9e-4;
+#     every other tensor of that step <= 1e-4) -> 1e-3.
+# A structural error of the data-parallel step (a missing moment all-reduce, a missing 1 / world on ANY parameter group) is >= 10 %.
+GRAD_TOL = {"dccrn": 1e-5, "nsvae": 1e-4, "twophase": 1e-5}
+GRAD_TOL_KEY = {"prelu.weight": 1e-4, "encoders.0.conv.conv_re.weight": 1e-3, "encoders.0.conv.conv_im.weight": 1e-3}
+
+
+def _tol(kind, key):
+    t = GRAD_TOL[kind]
+    for suffix, v in GRAD_TOL_KEY.items():
+        if key.endswith(suffix):
+            t = max(t, v)
+    return t
+
+
 STEPS = {"dccrn": (_train_step, KEYS, BUFS), "nsvae": (_nsvae_step, NS_KEYS, NS_BUFS), "twophase": (_twophase_step, TP_KEYS, TP_BUFS)}
 
 
