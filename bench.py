@@ -308,15 +308,49 @@ def self_launch(n_gpus: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log(f"self-launch: {' '.join(cmd)}")
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    import signal
+    import threading
+    # own session: the launcher and its N ranks form one process group that can be ended as a whole -- on SIGINT / SIGTERM of
+    # this parent, and at an overall deadline (a hung rank must not block the relay loop for ever): IDV_BENCH_DEADLINE seconds
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    state = {"why": None}
+
+    def end_group(why):
+        if proc.poll() is None:
+            state["why"] = why
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(proc.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    break
+                try:
+                    proc.wait(timeout=10)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+
+    deadline = float(os.environ.get("IDV_BENCH_DEADLINE", "1500"))
+    timer = threading.Timer(deadline, end_group, args=(f"deadline of {deadline:.0f} s",))
+    timer.daemon = True
+    timer.start()
+    old = {sig: signal.signal(sig, lambda n, f: (end_group(f"signal {n}"), sys.exit(128 + n))) for sig in (signal.SIGINT, signal.SIGTERM)}
     json_line = None
-    for line in proc.stdout:
-        line = line.rstrip("\n")
-        if line.startswith("{") and '"metric"' in line:
-            json_line = line
-        elif line:
-            print(line, file=sys.stderr, flush=True)
-    rc = proc.wait()
+    try:
+        for line in proc.stdout:
+            line = line.rstrip("\n")
+            if line.startswith("{") and '"metric"' in line:
+                json_line = line
+            elif line:
+                print(line, file=sys.stderr, flush=True)
+        rc = proc.wait()
+    finally:
+        timer.cancel()
+        end_group("launcher exit")
+        for sig, h in old.items():
+            signal.signal(sig, h)
+    if state["why"] and state["why"] != "launcher exit":
+        log(f"self-launch: ranks ended by the launcher ({state['why']})")
+        return rc if rc else 1
     if rc == 0 and json_line is None:
         log("self-launch: the ranks exited 0 without a JSON line")
         return 1
