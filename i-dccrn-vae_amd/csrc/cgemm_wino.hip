@@ -1,0 +1,438 @@
+// cgemm_wino: the complex ConvTranspose2d contraction of cgemm_gauss.hip (three real products per complex product) with the
+// FREQUENCY taps in Winograd minimal-filtering form: 7 instead of 10 real MFMA products per (input channel, pair of input rows).
+//
+// The reference's decoder block is a (5, 2)-tap transposed convolution with stride (2, 1) (model/complex_progress.py:222-279,
+// model/pvae_module.py:72-93).  Per input row m it feeds two output rows,
+//     out[2m]     = W4 x[m-1] + W2 x[m] + W0 x[m+1]          (even taps: a 3-tap stride-1 correlation over the input rows)
+//     out[2m + 1] =             W3 x[m] + W1 x[m+1]          (odd taps:  a 2-tap one)
+// (W_kf = the real 1 x 2 time-tap pair of frequency tap kf, applied by ONE v_mfma_f32_32x32x2_f32 whose two k are the two time
+// taps, exactly as in cgemm.hpp).  cgemm_gauss.hip spends 5 MFMAs per input row = 10 per pair of rows.  For the pair (m, m+1)
+// with d0..d3 = x[m-1..m+2]:
+//     F(2,3)   M1 = (d0 - d2) W4            M2 = (d1 + d2) (W4 + W2 + W0)/2     M3 = (d2 - d1) (W4 - W2 + W0)/2    M4 = (d1 - d3) W0
+//              out[2m] = M1 + M2 + M3       out[2m + 2] = M2 - M3 - M4
+//     F(2,2)   N1 = (d2 - d1) (-W3)         N2 = d2 (W3 + W1)                   N3 = (d2 - d3) W1
+//              out[2m + 1] = N1 + N2        out[2m + 3] = N2 - N3
+// -- seven products on SIX transformed rows (d2 - d1 serves M3 and N1).  The transformed rows are formed once per staged element
+// at the LDS write (where cgemm_gauss already forms s = x_r + x_i), the transformed taps once per parameter update by
+// idv_pack_ctconv_wino, the output transform is register-local in the epilogue.  All factors are 1 or 1/2: the transforms are
+// exact in fp32 up to the rounding of the sums (measured: DESIGN.md 3.1d).
+//
+// Two kinds of workgroup tiles (template PH), because an MFMA's accumulators live in the 256 AGPRs = at most 16 tiles per wave
+// (with more, hipcc swaps the rest through the AGPRs around every MFMA): PH = 0 computes the EVEN output rows of a pair of input
+// rows (F(2,3): 4 products x 3 Gauss planes = 12 accumulator tiles per wave, 4 transformed patch rows), PH = 1 the ODD rows
+// (F(2,2): 3 x 3 = 9 tiles, 3 transformed rows).  Per wave: 32 complex output channels x 2 output rows x ONE 32-column tile.
+// Weights: 4 floats per (channel, plane) and lane as ONE 16-byte load -- one vector-memory instruction per 4 / 3 MFMAs
+// (cgemm_gauss: five per ten).
+#include <cstdlib>
+#include "cgemm.hpp"
+#include "../../include/idccrn_hip.h"
+
+namespace {
+
+struct WinoArgs {
+    const float* x0;      // planar [2][C0][Fin][Jp]
+    const float* x1;      // optional skip source, planar [2][C1][Fin][Jp] (same pitch, x1_div == 1)
+    int C0, C1;
+    int Fin, Fout;
+    int J, Jp, Tp;
+    const float* wfrag;   // [phase 2][cotiles][units = Cin_pad * 3][64][4]: unit (ci, p), the phase's 4 / 3 (+ pad) transformed taps
+    int UN;               // units per co tile as packed (Cin rounded up to the pack granularity, x 3)
+    const float* epi;     // as cgemm_gauss: [cotiles * 32][8]
+    int has_fold;
+    const float* slope;
+    float* out;           // planar [2][Cout][Fout][Jp]
+    int Cout, cotiles;
+    int tshift, t_valid;
+    const float* add;     // optional addend (see cgemm_gauss.hip)
+    int add_div, add_Jp;
+    int jtiles, ftiles, mblocks;
+};
+
+constexpr int WCIK = 4;          // pack granularity in complex input channels (= cgemm_gauss's: shared `supported` rule); the kernel's K
+                                 // chunk CIK divides it (2: the weight ring of a chunk is 48 registers beside 336 accumulator registers)
+// transformed row tq = A + cb B of the raw rows d0..d3 (patch rows m0 - 1 .. m0 + 2); product q pairs tap q with row q
+//   PH 0 (even rows):  d0 - d2,  d1 + d2,  d2 - d1,  d1 - d3     taps  W4, (W4 + W2 + W0)/2, (W4 - W2 + W0)/2, W0
+//   PH 1 (odd rows):   d1 - d2,  d2,       d2 - d3               taps  W3, W3 + W1, W1
+template <int PH> __device__ __forceinline__ int wino_ra(int tq) { return PH == 0 ? (tq == 0 ? 0 : (tq == 2 ? 2 : 1)) : (tq == 0 ? 1 : 2); }
+template <int PH> __device__ __forceinline__ int wino_rb(int tq) { return PH == 0 ? (tq == 2 ? 1 : (tq == 3 ? 3 : 2)) : (tq == 0 ? 2 : 3); }
+template <int PH> __device__ __forceinline__ float wino_cb(int tq) { return PH == 0 ? (tq == 1 ? 1.f : -1.f) : (tq == 1 ? 0.f : -1.f); }
+
+template <int PH, int WM, int WN, int CIK, int NBUF>
+__global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoArgs a) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TR = PH == 0 ? 4 : 3;           // transformed patch rows per (channel, plane) = products per (channel, plane)
+    constexpr int NP = TR;
+    constexpr int JT = 32 * WN;
+    constexpr int PS = JT + 8;                    // patch row: the 16-byte aligned span j0-4 .. j0+JT+3
+    constexpr int COL0 = 4;
+    constexpr int PS4 = PS / 4;
+    constexpr int NS = CIK * TR * PS4;            // staging items per chunk: one float4 slot of one TRANSFORMED row of one channel
+    constexpr int NLD = (NS + NT - 1) / NT;
+    constexpr int NE = CIK * 3 * TR * PS;         // patch floats per chunk
+    constexpr int UNITS = CIK * 3;                // pipeline units per chunk: (channel, plane)
+    static_assert(NLD <= 4, "staging registers");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // block order as cgemm_gauss (map_ft form): all frequency tiles of a column block on ONE XCD, the MB co-tile blocks of a tile
+    // on consecutive slots of it
+    const int MB = a.mblocks, FTn = a.ftiles;
+    const int bid = blockIdx.x;
+    const int per = 8 * MB * FTn;
+    const int sg = bid / per, rem = bid - sg * per;
+    const int v = rem >> 3;
+    const int jt = sg * 8 + (rem & 7);
+    const int ft = v / MB;
+    const int mblk = v - ft * MB;
+    if (jt >= a.jtiles) return;
+    const int j0 = jt * JT;
+    const int ct = mblk * WM + wm;
+    const bool ct_ok = ct < a.cotiles;
+    const int m0 = 2 * ft;                        // first input row of the tile; raw patch rows m0 - 1 .. m0 + 2
+
+    const int Cin = a.C0 + a.C1;
+    const int nchunk = (Cin + CIK - 1) / CIK;
+
+    f32x16 acc[NP][3];
+#pragma unroll
+    for (int w = 0; w < NP; ++w)
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[w][p3][r] = 0.f;
+
+    // ---- staging.  An item = 4 consecutive columns of one transformed row of one channel: it loads the real and imaginary
+    // values of its two raw rows (A, B), forms T = A + cb B for the planes x_r and x_i and s = T_r + T_i, writes three float4.
+    f32x4 sar[NLD], sai[NLD], sbr[NLD], sbi[NLD];
+    unsigned voffa[NLD], voffb[NLD];  // float offsets of the two raw slots relative to the chunk's first real plane
+    unsigned okbits = 0;              // 4 column bits (a) | 4 column bits (b) per item
+    unsigned ldsoff[NLD];
+    float cbv[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + i * NT;
+        const int row = e / PS4, c4 = e - row * PS4;
+        const int cil = row / TR, tq = row - cil * TR;
+        const int fa = m0 - 1 + wino_ra<PH>(tq), fb = m0 - 1 + wino_rb<PH>(tq);
+        const int jv = j0 - 4 + 4 * c4;
+        const bool oka = (e < NS) && fa >= 0 && fa < a.Fin;
+        const bool okb = (e < NS) && wino_cb<PH>(tq) != 0.f && fb >= 0 && fb < a.Fin;
+        unsigned ba = 0, bb = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool cok = jv + q >= 0 && jv + q < a.J;
+            if (oka && cok) ba |= 1u << q;
+            if (okb && cok) bb |= 1u << q;
+        }
+        okbits |= (ba | (bb << 4)) << (8 * i);
+        voffa[i] = ba ? (unsigned)((cil * a.Fin + fa) * a.Jp + jv) : 0u;      // a dead slot loads mapped memory (offset 0)
+        voffb[i] = bb ? (unsigned)((cil * a.Fin + fb) * a.Jp + jv) : 0u;
+        cbv[i] = wino_cb<PH>(tq);
+        ldsoff[i] = (unsigned)(((cil * 3) * TR + tq) * PS + 4 * c4);
+    }
+    auto stage_load = [&](int chunk) {
+        const int ci0 = chunk * CIK;
+        const bool from0 = ci0 < a.C0;
+        const float* br = from0 ? a.x0 + (size_t)ci0 * a.Fin * a.Jp : a.x1 + (size_t)(ci0 - a.C0) * a.Fin * a.Jp;
+        const float* bi = from0 ? br + (size_t)a.C0 * a.Fin * a.Jp : br + (size_t)a.C1 * a.Fin * a.Jp;
+        const int cvalid = (from0 ? a.C0 : Cin) - ci0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const bool dead = (tid + i * NT) / (TR * PS4) >= cvalid;
+            const unsigned oa = dead ? 0u : voffa[i], ob = dead ? 0u : voffb[i];
+            sar[i] = *(const f32x4*)(br + oa);
+            sai[i] = *(const f32x4*)(bi + oa);
+            sbr[i] = *(const f32x4*)(br + ob);
+            sbi[i] = *(const f32x4*)(bi + ob);
+        }
+    };
+    auto stage_store = [&](float* dst, int chunk) {
+        const int ci0s = chunk * CIK;
+        const int cvalid = (ci0s < a.C0 ? a.C0 : Cin) - ci0s;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) asm volatile("" ::"v"(sar[i]), "v"(sai[i]), "v"(sbr[i]), "v"(sbi[i]));
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * NT;
+            unsigned bits = (okbits >> (8 * i)) & 255u;
+            if (e / (TR * PS4) >= cvalid) bits = 0u;
+            f32x4 vr, vi, vs;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float ar = (bits >> q) & 1u ? sar[i][q] : 0.f, ai = (bits >> q) & 1u ? sai[i][q] : 0.f;
+                const float br_ = (bits >> (4 + q)) & 1u ? sbr[i][q] : 0.f, bi_ = (bits >> (4 + q)) & 1u ? sbi[i][q] : 0.f;
+                vr[q] = ar + cbv[i] * br_;
+                vi[q] = ai + cbv[i] * bi_;
+                vs[q] = vr[q] + vi[q];
+            }
+            if (e < NS) {
+                float* d = dst + ldsoff[i];
+                *(f32x4*)d = vs;
+                *(f32x4*)(d + TR * PS) = vr;
+                *(f32x4*)(d + 2 * TR * PS) = vi;
+            }
+        }
+    };
+
+    // ---- weights: per unit ONE 16-byte load (the 4 / 3 taps of this phase); one register set, a unit's fragment re-loaded with
+    // its next use right after the unit's MFMAs consumed it (as cgemm_gauss, rotated by one unit)
+    const f32x4* wbase = (const f32x4*)a.wfrag + ((size_t)PH * a.cotiles + (ct_ok ? ct : 0)) * a.UN * 64 + lane;
+    f32x4 a_w[UNITS];
+
+    const int bcol = wn * 32 + (lane & 31) + (lane >> 5) + COL0 + a.tshift;
+    auto load_b = [&](const float* P, int u, float (&dst)[TR]) {
+#pragma unroll
+        for (int tq = 0; tq < TR; ++tq) dst[tq] = P[(u * TR + tq) * PS + bcol];
+    };
+
+    stage_load(0);
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) a_w[u] = wbase[(size_t)u * 64];
+    stage_store(smem, 0);
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) asm volatile("" : "+v"(a_w[u]));
+    __syncthreads();
+
+    constexpr int UMID = UNITS / 2;
+    float b_cur[TR], b_nxt[TR];
+    int ibuf = 0;
+    if (NBUF == 3) load_b(smem, 0, b_cur);
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const float* P = smem + ibuf * NE;
+        const int inext = (ibuf + 1 == NBUF) ? 0 : ibuf + 1;
+        float* Pn = smem + inext * NE;
+        const int nxt = (chunk + 1 < nchunk) ? chunk + 1 : chunk;
+        const f32x4* wnx = wbase + (size_t)nxt * UNITS * 64;
+        const f32x4* wcu = wbase + (size_t)chunk * UNITS * 64;
+        if (NBUF == 2) load_b(P, 0, b_cur);
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int p3 = u % 3;
+            // product q = tap q x transformed row q
+            acc[0][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u][0], b_cur[0], acc[0][p3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NBUF == 3 && u == UNITS - 1) __syncthreads();
+            if (u + 1 < UNITS)
+                load_b(P, u + 1, b_nxt);
+            else if (NBUF == 3)
+                load_b(Pn, 0, b_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u == 0) stage_load(nxt);
+            if (u == (NBUF == 3 ? UMID : UNITS - 1)) stage_store(Pn, nxt);
+            acc[1][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u][1], b_cur[1], acc[1][p3], 0, 0, 0);
+            acc[2][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u][2], b_cur[2], acc[2][p3], 0, 0, 0);
+            if (NP == 4) acc[NP - 1][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u][3], b_cur[NP - 1], acc[NP - 1][p3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u == 0)
+                a_w[UNITS - 1] = wcu[(size_t)(UNITS - 1) * 64];
+            else
+                a_w[u - 1] = wnx[(size_t)(u - 1) * 64];
+            if (u + 1 < UNITS || NBUF == 3) {
+#pragma unroll
+                for (int tq = 0; tq < TR; ++tq) b_cur[tq] = b_nxt[tq];
+            }
+        }
+        if (NBUF == 2) __syncthreads();
+        ibuf = inext;
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    if (!ct_ok) return;
+    const float slope = a.slope ? *a.slope : 1.0f;
+    const bool has_act = a.slope != nullptr;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int j = j0 + wn * 32 + l31;
+    const int bj = j / a.Tp, tp = j - bj * a.Tp;
+    const bool keep = (tp >= 1) && (tp <= a.t_valid);
+    const bool inb = j < a.J;
+    const int ja = j - (bj - bj / a.add_div) * a.Tp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const f32x4 e0 = *(const f32x4*)(a.epi + (size_t)co * 8);
+        const float e4 = a.epi[(size_t)co * 8 + 4], e5 = a.epi[(size_t)co * 8 + 5];
+        const bool cok = co < a.Cout;
+        float t[2][3];                       // this phase's two output rows x Gauss products
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) {
+            if (PH == 0) {
+                const float M1 = acc[0][p3][r], M2 = acc[1][p3][r], M3 = acc[2][p3][r], M4 = acc[NP - 1][p3][r];
+                t[0][p3] = M1 + M2 + M3;
+                t[1][p3] = M2 - M3 - M4;
+            } else {
+                const float N1 = acc[0][p3][r], N2 = acc[1][p3][r], N3 = acc[2][p3][r];
+                t[0][p3] = N1 + N2;
+                t[1][p3] = N2 - N3;
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int fo = 2 * m0 + PH + 2 * rt;
+            if (fo >= a.Fout) continue;
+            float re = t[rt][0] - t[rt][2], im = t[rt][0] + t[rt][1];
+            if (a.add && cok && inb) {
+                re += a.add[((size_t)co * a.Fout + fo) * a.add_Jp + ja];
+                im += a.add[((size_t)(a.Cout + co) * a.Fout + fo) * a.add_Jp + ja];
+            }
+            float yr, yi;
+            if (a.has_fold) {
+                yr = e0[0] * re + e0[1] * im + e4;
+                yi = e0[2] * re + e0[3] * im + e5;
+            } else {
+                yr = re + e4;
+                yi = im + e5;
+            }
+            if (has_act) {
+                yr = yr >= 0.f ? yr : slope * yr;
+                yi = yi >= 0.f ? yi : slope * yi;
+            }
+            yr = keep ? yr : 0.f;
+            yi = keep ? yi : 0.f;
+            if (cok && inb) {
+                a.out[((size_t)co * a.Fout + fo) * a.Jp + j] = yr;
+                a.out[((size_t)(a.Cout + co) * a.Fout + fo) * a.Jp + j] = yi;
+            }
+        }
+    }
+}
+
+// fragment element (phase, ct, unit = ci * 3 + p, lane, q): tap q of the phase's transformed taps, lane = kt * 32 + col supplies
+// co = ct * 32 + col.  Index conventions (transposed / conj, kt) as pack_cconv_gauss_kernel.
+__global__ void pack_ctconv_wino_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im, int Cout, int Cin_total,
+                                        int Cin_used, int transposed, int conj, int UN, int cotiles, float* __restrict__ wfrag) {
+    const long long n = 2LL * cotiles * UN * 64;                  // one thread per (phase, ct, unit, lane): 4 floats
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        long long t = idx >> 6;
+        const int unit = (int)(t % UN); t /= UN;
+        const int ct = (int)(t % cotiles);
+        const int ph = (int)(t / cotiles);
+        const int h = lane >> 5, co = ct * 32 + (lane & 31);
+        const int ci = unit / 3, p3 = unit % 3;
+        float W[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (co < Cout && ci < Cin_used) {
+            const int kt = transposed ? 1 - h : h;
+#pragma unroll
+            for (int kf = 0; kf < 5; ++kf) {
+                const size_t off = transposed ? (((size_t)ci * Cout + co) * 5 + kf) * 2 + kt
+                                              : (((size_t)co * Cin_total + ci) * 5 + kf) * 2 + kt;
+                const float wr = w_re[off], wi = conj ? -w_im[off] : w_im[off];
+                W[kf] = p3 == 0 ? wr : (p3 == 1 ? wi - wr : wr + wi);
+            }
+        }
+        f32x4 o;
+        if (ph == 0) {
+            o[0] = W[4];
+            o[1] = 0.5f * (W[4] + W[2] + W[0]);
+            o[2] = 0.5f * (W[4] - W[2] + W[0]);
+            o[3] = W[0];
+        } else {
+            o[0] = W[3];
+            o[1] = W[3] + W[1];
+            o[2] = W[1];
+            o[3] = 0.f;
+        }
+        *(f32x4*)(wfrag + idx * 4) = o;
+    }
+}
+
+template <int PH, int WM, int WN, int CIK>
+int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
+    static_assert(WCIK % CIK == 0, "a K chunk never straddles the pack granularity (nor, with it, the two sources)");
+    constexpr int TR = PH == 0 ? 4 : 3;
+    constexpr int JT = 32 * WN;
+    constexpr int NE = CIK * 3 * TR * (JT + 8);
+    constexpr int NBUF = (3 * NE * sizeof(float) <= 156 * 1024) ? 3 : 2;
+    constexpr size_t smem = NBUF * NE * sizeof(float);
+    WinoArgs b = a;
+    b.jtiles = (a.J + JT - 1) / JT;
+    b.ftiles = (a.Fin + 1) / 2;
+    b.mblocks = (a.cotiles + WM - 1) / WM;
+    const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
+    if (nblk > 0x7fffffffLL) return IDV_EINVAL;
+    auto k = ctconv_wino_kernel<PH, WM, WN, CIK, NBUF>;
+    // more than half a CU's LDS: one workgroup per CU (the kernel is built for one: 192 / 144 accumulator registers)
+    const size_t smem_req = smem > 84 * 1024 ? smem : 84 * 1024;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req) != hipSuccess) return IDV_ELAUNCH;
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(WM * WN * 64), smem_req, st, b);
+    return idv_launch_status();
+}
+
+// even rows, then odd rows: two launches per layer (the second reads the same raw rows from the L2 / Infinity Cache)
+template <int WM, int WN, int CIK>
+int launch_wino(const WinoArgs& a, hipStream_t st) {
+    if (int rc = launch_wino_ph<0, WM, WN, CIK>(a, st)) return rc;
+    return launch_wino_ph<1, WM, WN, CIK>(a, st);
+}
+
+const bool USE_WINO = [] { const char* e = getenv("IDV_WINO"); return !e || e[0] != '0'; }();
+
+}  // namespace
+
+// 1 if the Winograd form serves this transposed-conv layer: what cgemm_gauss serves, with more than one input row
+extern "C" int idv_ctconv_wino_supported(int C0, int C1, int Cout, int Fin) {
+    if (!USE_WINO || Fin < 2) return 0;
+    return idv_cconv_gauss_supported(C0, C1, Cout);
+}
+
+extern "C" long long idv_ctconv_wino_wfrag_floats(int Cout, int cin_used) {
+    const long long cotiles = (Cout + 31) / 32, cpad = (cin_used + WCIK - 1) / WCIK * WCIK;
+    return 2 * cotiles * cpad * 3 * 64 * 4;               // [phase][co tile][unit][lane][4]
+}
+
+// configuration id for bench.py / profiles: 4 WM WN (e.g. 441 = four co tiles x one column group)
+extern "C" int idv_ctconv_wino_config(int Cin, int Cout) {
+    (void)Cin;
+    return Cout >= 128 ? 441 : (Cout > 32 ? 422 : 414);
+}
+
+// Winograd-transformed Gauss planes of a ComplexConvTranspose2d weight (w_*: [Cin][Cout][5][2], transposed = 1) or of the adjoint
+// of a ComplexConv2d (w_*: [Cout'][Cin'][5][2] read as [Cin = Cout'][..], transposed = 0, conj = 1: the data-gradient operator),
+// conventions as idv_pack_cconv_gauss.  The epilogue table is idv_pack_cconv_gauss's.
+extern "C" int idv_pack_ctconv_wino(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used, int transposed,
+                                    int conj, float* wfrag, void* stream) {
+    if (!w_re || !w_im || !wfrag || Cout <= 0 || Cin_used <= 0 || Cin_used > Cin_total) return IDV_EINVAL;
+    const int cotiles = (Cout + 31) / 32;
+    const int UN = (Cin_used + WCIK - 1) / WCIK * WCIK * 3;
+    const long long n = 2LL * cotiles * UN * 64;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_ctconv_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_re, w_im, Cout, Cin_total, Cin_used,
+                       transposed, conj, UN, cotiles, wfrag);
+    return idv_launch_status();
+}
+
+// idv_cconv2d_gauss_fwd (transposed = 1, no statistics, x1_div == 1) on the Winograd kernel: same result up to the rounding of
+// the transforms.  wfrag from idv_pack_ctconv_wino, epi / has_fold from idv_pack_cconv_gauss.  Requires 16-byte aligned sources
+// with Jp % 4 == 0 and, with a second source, the same pitch (the callers' planar buffers are).  Reference:
+// model/complex_progress.py:222-279 (+ :161-209 and pvae_module.py:82 for the epilogue).
+extern "C" int idv_ctconv2d_wino_fwd(const float* x0, int C0, const float* x1, int C1, const float* wfrag, const float* epi, int has_fold,
+                                     const float* prelu_slope, float* out, int tshift, int Cout, int Fin, int B, int Tp, int Jp,
+                                     int t_valid_out, const float* addend, int addend_div, int addend_Jp, void* stream) {
+    if (!x0 || !wfrag || !epi || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    if (addend && (addend_div < 1 || B % addend_div || addend_Jp < (B / addend_div) * Tp)) return IDV_EINVAL;
+    if (C1 > 0 && !x1) return IDV_EINVAL;
+    if (tshift != 0 && tshift != -1) return IDV_EINVAL;
+    if (!idv_ctconv_wino_supported(C0, C1, Cout, Fin)) return IDV_EINVAL;
+    if ((Jp & 3) || (reinterpret_cast<uintptr_t>(x0) & 15) || (C1 > 0 && (reinterpret_cast<uintptr_t>(x1) & 15))) return IDV_EINVAL;
+    WinoArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1;
+    a.Fin = Fin; a.Fout = 2 * Fin - 1;
+    a.J = B * Tp; a.Jp = Jp; a.Tp = Tp;
+    a.wfrag = wfrag; a.UN = (C0 + C1 + WCIK - 1) / WCIK * WCIK * 3; a.epi = epi; a.has_fold = has_fold; a.slope = prelu_slope; a.out = out;
+    a.Cout = Cout; a.cotiles = (Cout + 31) / 32;
+    a.tshift = tshift; a.t_valid = t_valid_out;
+    a.add = addend; a.add_div = addend ? addend_div : 1; a.add_Jp = addend_Jp;
+    if (Jp < a.J) return IDV_EINVAL;
+    if ((long long)WCIK * Fin * (long long)Jp >= 0xffffffffLL) return IDV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    switch (idv_ctconv_wino_config(C0 + C1, Cout)) {
+        case 441: return launch_wino<4, 1, 4>(a, st);
+        case 422: return launch_wino<2, 2, 4>(a, st);
+        default: return launch_wino<1, 4, 4>(a, st);
+    }
+}

@@ -257,10 +257,30 @@ def pack_cconv_gauss(w_re, w_im, b_re, b_im, fold, cin_used: Optional[int] = Non
         # versa: same memory, the other interpretation, W_i negated (idv_pack_cconv_adjoint does the same)
         call("idv_pack_cconv_gauss", p(w_re), p(w_im), p(None), p(None), p(None), i(cout), i(cin_total), i(cin_used),
              i(1 if transposed else 0), i(1), p(wfrag), p(epi), stream_ptr())
-        return wfrag, epi, 0
-    call("idv_pack_cconv_gauss", p(w_re.contiguous()), p(w_im.contiguous()), p(b_re.contiguous()), p(b_im.contiguous()), p(fold),
+        return wfrag, epi, 0, _pack_wino(w_re, w_im, cout, cin_total, cin_used, transposed, 1)
+    w_re, w_im = w_re.contiguous(), w_im.contiguous()
+    call("idv_pack_cconv_gauss", p(w_re), p(w_im), p(b_re.contiguous()), p(b_im.contiguous()), p(fold),
          i(cout), i(cin_total), i(cin_used), i(1 if transposed else 0), i(0), p(wfrag), p(epi), stream_ptr())
-    return wfrag, epi, (1 if fold is not None else 0)
+    return wfrag, epi, (1 if fold is not None else 0), _pack_wino(w_re, w_im, cout, cin_total, cin_used, transposed, 0)
+
+
+# fp32 transposed convs with Winograd-transformed frequency taps on top of the three-product form (csrc/cgemm_wino.hip):
+# 7 instead of 10 real products per input channel and pair of input rows.  IDV_WINO=0 (or ops.WINO = False) keeps cgemm_gauss.
+WINO = os.environ.get("IDV_WINO", "1") != "0"
+WINO_CFG = 4000000               # LAUNCH_LOG ids: WINO_CFG + idv_ctconv_wino_config
+
+
+def _pack_wino(w_re, w_im, cout: int, cin_total: int, cin_used: int, transposed: bool, conj: int):
+    """Winograd-transformed Gauss planes for a transposed operator (a ComplexConvTranspose2d, or the adjoint of a ComplexConv2d:
+    transposed here is the OPERATOR's mode); None where the kernel does not apply."""
+    if not (WINO and transposed):
+        return None
+    n = int(_ll_fn("idv_ctconv_wino_wfrag_floats")(i(cout), i(cin_used)))
+    wf = torch.empty(n, dtype=torch.float32, device=w_re.device)
+    # same flags as idv_pack_cconv_gauss gets for this operator: mode 1 = the tensor is read as [Cin][Cout][5][2] (a transposed
+    # conv's own weight, or a conv's [Cout'][Cin'] weight seen from its adjoint), conj negates W_i (adjoint)
+    call("idv_pack_ctconv_wino", p(w_re), p(w_im), i(cout), i(cin_total), i(cin_used), i(1), i(conj), p(wf), stream_ptr())
+    return wf
 
 
 def pack_cconv_gauss_skip_part(w_re, w_im, c0: int):
@@ -274,7 +294,7 @@ def pack_cconv_gauss_skip_part(w_re, w_im, c0: int):
     epi = torch.empty(int(lib.idv_cconv_gauss_epi_rows(i(cout))) * 8, dtype=torch.float32, device=wr.device)
     call("idv_pack_cconv_gauss", p(wr), p(wi), p(None), p(None), p(None), i(cout), i(cin), i(cin), i(1), i(0), p(wfrag), p(epi),
          stream_ptr())
-    return wfrag, epi, 0
+    return wfrag, epi, 0, _pack_wino(wr, wi, cout, cin, cin, True, 0)
 
 
 def bf16_supported(transposed: bool, c0: int, c1: int, skip_div: int, cout: int) -> bool:
@@ -483,8 +503,17 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
             ev1.record()
             LAUNCH_LOG.append((cfg, macs, ev0, ev1))
         return out
-    if gauss is not None:
-        # fp32: three real products per complex product (csrc/cgemm_gauss.hip); gauss = (wfrag3, epi, has_fold)
+    if (gauss is not None and transposed and WINO and len(gauss) > 3 and gauss[3] is not None and stats is None and skip_div == 1
+            and (skip is None or skip.Jp == x.Jp) and x.Jp % 4 == 0
+            and L.lib().idv_ctconv_wino_supported(i(x.C), i(c1), i(cout), i(x.F))):
+        # fp32 transposed conv: Winograd-transformed frequency taps on top of the three products (csrc/cgemm_wino.hip)
+        if LAUNCH_LOG is not None:
+            cfg = WINO_CFG + L.lib().idv_ctconv_wino_config(i(x.C + c1), i(cout))
+        call("idv_ctconv2d_wino_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1), p(gauss[3]), p(gauss[1]),
+             i(gauss[2]), p(slope), out.ptr(), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out),
+             addend.ptr() if addend is not None else p(None), i(addend_div), i(addend.Jp if addend is not None else 0), stream_ptr())
+    elif gauss is not None:
+        # fp32: three real products per complex product (csrc/cgemm_gauss.hip); gauss = (wfrag3, epi, has_fold[, wino fragments])
         if LAUNCH_LOG is not None:
             cfg = L.lib().idv_cconv_gauss_config(i(1 if transposed else 0), i(x.C + c1), i(cout), i(x.F))
         swork = _stats_work(stats, cout)

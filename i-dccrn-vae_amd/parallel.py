@@ -97,6 +97,7 @@ class GradAllReduce:
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
         self._tab = [None] * len(self.buckets)
         self._present = [None] * len(self.buckets)
+        self._checked = [False] * len(self.buckets)
         self._scale = 1.0
 
     def bucket(self, bi: int = 0):
@@ -122,19 +123,34 @@ class GradAllReduce:
             all_reduce_sum_(flat, self.group)
             self._scale = 1.0 / world
         if into_grads:
-            for p in bucket:
-                if p.grad is None:
-                    p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
-                elif not p.grad.is_contiguous():
-                    p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
-            optim.bucket_scatter(tab, [p.grad for p in bucket], flat, self._scale)
+            # a parameter without a gradient keeps none (the reference's single-device optimiser skips it; see _check_presence)
+            optim.bucket_scatter(tab, grads, flat, self._scale)
+            for p, g in zip(bucket, grads):
+                if g is not None and g is not p.grad:
+                    p.grad = g                          # a non-contiguous .grad was averaged in its contiguous copy
+
+    def _check_presence(self, bucket, world: int):
+        """Once per bucket: every rank must agree on WHICH parameters have a gradient.  A parameter without one is skipped --
+        it keeps ``.grad = None`` and the optimiser leaves it alone, as on the reference's single device (e.g. the
+        constructed-but-unused ``linear`` conv of standard_DCCRN, pvae_module.py:158) -- which is only right if no other rank
+        has a gradient for it.  One small all-reduce and one host read, on the first step only."""
+        flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in bucket], dtype=torch.float32, device=bucket[0].device)
+        all_reduce_sum_(flags, self.group)
+        got = flags.cpu().tolist()
+        bad = [k for k, v in enumerate(got) if v not in (0.0, float(world))]
+        if bad:
+            raise RuntimeError(f"GradAllReduce: parameters {bad[:8]} of a bucket have a gradient on some ranks only; the data-parallel "
+                               "step expects the same graph on every rank")
 
     def reduce(self, into_grads: bool = True):
-        """Average ``.grad`` over the ranks (parameters without a gradient on this rank contribute zeros)."""
+        """Average ``.grad`` over the ranks; a parameter without a gradient (on every rank: checked once) keeps none."""
         world = _world(self.group)
         if not _active(self.group):
             return
         for bi, bucket in enumerate(self.buckets):
+            if not self._checked[bi]:
+                self._check_presence(bucket, world)
+                self._checked[bi] = True
             if bucket[0].is_cuda:
                 self._reduce_device(bi, bucket, world, into_grads)
                 continue
@@ -155,9 +171,7 @@ class GradAllReduce:
             o = 0
             for p in bucket:
                 k = p.numel()
-                if p.grad is None:
-                    p.grad = flat[o:o + k].view_as(p).clone()
-                else:
+                if p.grad is not None:
                     p.grad.copy_(flat[o:o + k].view_as(p))
                 o += k
 

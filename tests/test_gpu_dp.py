@@ -260,7 +260,7 @@ def test_two_ranks_equal_one_rank_full_batch(kind):
         for k in KEYS:
             ref = full_g[k].astype("float64")
             e = float(np.linalg.norm(grads[k].astype("float64") - ref)) / (float(np.linalg.norm(ref)) + 1e-30)
-            if e > GRAD_TOL[kind]:
+            if e > _tol(kind, k):
                 bad.append((rank, "grad", k, e))
         for k in BUFS:
             ref = full_b[k].astype("float64")
@@ -270,7 +270,7 @@ def test_two_ranks_equal_one_rank_full_batch(kind):
         for k, v in full_n.items():
             if k.endswith("conv_re.bias") or k.endswith("conv_im.bias"):
                 continue                          # bias in front of a batch norm: the true gradient is exactly zero
-            if abs(norms[k] - v) > 2 * GRAD_TOL[kind] * v + 1e-7:
+            if abs(norms[k] - v) > 2 * _tol(kind, k) * v + 1e-7:
                 bad.append((rank, "norm", k, norms[k], v))
     assert not bad, "\n".join(map(str, bad))
     # both ranks hold identical (averaged) gradients

@@ -109,6 +109,38 @@ def test_cconv_gauss(ops, causal, transposed, cin, cout, F, T, B, skip_c, skip_d
                gauss=True)
 
 
+@pytest.mark.parametrize("causal,cin,cout,F,T,B,skip_c,fold,slope", [
+    (True, 8, 40, 9, 37, 3, 0, True, 0.2),          # two co tiles x two column groups (ragged second co tile), odd row count
+    (True, 16, 128, 5, 30, 2, 0, False, None),      # four co tiles x one column group
+    (True, 8, 12, 17, 21, 5, 0, True, 0.3),         # one co tile x four column groups (128-column patch)
+    (True, 8, 8, 6, 30, 2, 8, False, None),         # even row count, skip concat (second source)
+    (True, 6, 4, 2, 9, 2, 0, False, 0.1),           # two input rows (one tile), channel count below the pack granularity
+    (True, 7, 36, 3, 45, 1, 0, True, None),         # odd channel count: ragged last K chunk
+    (False, 6, 4, 9, 9, 2, 0, False, None),         # non-causal taps (T + 1 output frames)
+    (True, 32, 32, 33, 645, 2, 32, False, 0.25),    # utterance-length columns, Tp = 646, column tail
+    (True, 256, 64, 17, 70, 2, 0, True, 0.25),      # a real layer width (dec3's channels)
+])
+def test_ctconv_wino(ops, causal, cin, cout, F, T, B, skip_c, fold, slope):
+    """The transposed conv with Winograd-transformed frequency taps (csrc/cgemm_wino.hip: F(2,3) on the even, F(2,2) on the odd
+    taps, on top of the three complex products) against the oracle's four real transposed convolutions AND against
+    cgemm_gauss_kernel, in its three workgroup shapes."""
+    keep, keep_log = ops.WINO, ops.LAUNCH_LOG
+    try:
+        ops.WINO = True
+        ops.LAUNCH_LOG = []
+        got = _conv_case(ops, causal, True, cin, cout, F, T, B, seed=61, fold=fold, slope=slope, skip_c=skip_c, gauss=True)
+        assert [c for c, *_ in ops.LAUNCH_LOG if c >= ops.WINO_CFG], "the Winograd kernel was not launched"
+        ops.WINO = False
+        ops.LAUNCH_LOG = []
+        ref = _conv_case(ops, causal, True, cin, cout, F, T, B, seed=61, fold=fold, slope=slope, skip_c=skip_c, gauss=True)
+        assert not [c for c, *_ in ops.LAUNCH_LOG if c >= ops.WINO_CFG]
+    finally:
+        ops.WINO, ops.LAUNCH_LOG = keep, keep_log
+    e = relerr(got, ref)
+    print(f"wino vs gauss kernel: {e:.2e}")
+    assert e < 5e-6
+
+
 def test_cconv_gauss_stats_and_adjoint(ops):
     """Train-mode moment sums of the three-product kernel = those of cgemm_kernel, and its adjoint (data gradient) form =
     the adjoint on cgemm_kernel, for a conv and a transposed conv."""

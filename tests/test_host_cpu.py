@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(amd):
     lib = L.lib()                                    # raises if the .so is missing or a symbol is absent
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.idv_abi_version() == 6          # 2: backward entry points; 3: split-image hand-over inside idv_clstm_fwd; 4: IDV_ECOOP status; 5: idv_cconv_gauss_config takes Cin, idv_lstm_stack2_f32 / idv_clstm_fwd2; 6: idv_bucket_*
+    assert lib.idv_abi_version() == 7          # 2: backward entry points; 3: split-image hand-over inside idv_clstm_fwd; 4: IDV_ECOOP status; 5: idv_cconv_gauss_config takes Cin, idv_lstm_stack2_f32 / idv_clstm_fwd2; 6: idv_bucket_*; 7: idv_ctconv_wino_*
     assert lib.idv_cconv_cck(ctypes.c_int(1)) == 2 and lib.idv_cconv_cck(ctypes.c_int(32)) == 4
     assert lib.idv_cconv_config(ctypes.c_int(1), ctypes.c_int(64), ctypes.c_int(1), ctypes.c_int(129)) == 1000001          # the one-output-channel vector-ALU kernel
     lib.idv_clstm_work_floats.restype = ctypes.c_longlong
@@ -272,12 +272,17 @@ def test_bench_self_launch_starts_ranks_as_a_child_and_relays_rank0(monkeypatch,
     seen = {}
 
     class FakeProc:
-        def __init__(self, cmd, env=None, stdout=None, text=None):
-            seen["cmd"], seen["env"] = cmd, env
+        pid = 0
+
+        def __init__(self, cmd, env=None, stdout=None, text=None, start_new_session=False):
+            seen["cmd"], seen["env"], seen["session"] = cmd, env, start_new_session
             self.stdout = io.StringIO('rank noise\n{"metric": "m", "value": 1.5, "n_gpus": 4, "rccl_ranks": 4}\ntrailing\n')
 
-        def wait(self):
+        def wait(self, timeout=None):
             return 0
+
+        def poll(self):
+            return 0                               # already exited: the launcher's clean-up has nothing to end
     import subprocess
     monkeypatch.setattr(subprocess, "Popen", FakeProc)
     monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--workload", "nsvae_train"])
@@ -292,6 +297,7 @@ def test_bench_self_launch_starts_ranks_as_a_child_and_relays_rank0(monkeypatch,
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--workload", "nsvae_train"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["session"] is True                                      # own process group: ended as a whole on a signal / deadline
     assert ("torch" in _sys.modules) == had_torch                       # the launcher itself imports no torch
 
 
