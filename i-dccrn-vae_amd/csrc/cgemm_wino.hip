@@ -43,6 +43,8 @@ struct WinoArgs {
     float* out;           // planar [2][Cout][Fout][Jp]
     int Cout, cotiles;
     int tshift, t_valid;
+    double* stats;        // train mode: [Cout][5] sums (r, i, rr, ii, ri) of conv + bias, or nullptr (as cgemm_gauss)
+    int stats_rep;        // > 1: that many replicas [rep][Cout][5] (power of two), one chosen per workgroup
     const float* add;     // optional addend (see cgemm_gauss.hip)
     int add_div, add_Jp;
     int jtiles, ftiles, mblocks;
@@ -57,7 +59,7 @@ template <int PH> __device__ __forceinline__ int wino_ra(int tq) { return PH == 
 template <int PH> __device__ __forceinline__ int wino_rb(int tq) { return PH == 0 ? (tq == 2 ? 1 : (tq == 3 ? 3 : 2)) : (tq == 0 ? 2 : 3); }
 template <int PH> __device__ __forceinline__ float wino_cb(int tq) { return PH == 0 ? (tq == 1 ? 1.f : -1.f) : (tq == 1 ? 0.f : -1.f); }
 
-template <int PH, int WM, int WN, int CIK, int NBUF>
+template <int PH, int WM, int WN, int CIK, int NBUF, bool STATS>
 __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoArgs a) {
     constexpr int NT = WM * WN * 64;
     constexpr int TR = PH == 0 ? 4 : 3;           // transformed patch rows per (channel, plane) = products per (channel, plane)
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
         const f32x4 e0 = *(const f32x4*)(a.epi + (size_t)co * 8);
         const float e4 = a.epi[(size_t)co * 8 + 4], e5 = a.epi[(size_t)co * 8 + 5];
         const bool cok = co < a.Cout;
+        float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         float t[2][3];                       // this phase's two output rows x Gauss products
 #pragma unroll
         for (int p3 = 0; p3 < 3; ++p3) {
@@ -296,6 +299,23 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
             if (cok && inb) {
                 a.out[((size_t)co * a.Fout + fo) * a.Jp + j] = yr;
                 a.out[((size_t)(a.Cout + co) * a.Fout + fo) * a.Jp + j] = yi;
+            }
+            if (STATS && inb && keep) {
+                st[0] += yr;
+                st[1] += yi;
+                st[2] += yr * yr;
+                st[3] += yi * yi;
+                st[4] += yr * yi;
+            }
+        }
+        if (STATS) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                float tsum = st[q];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o, 64);
+                if (l31 == 0 && cok)
+                    atomicAdd(&a.stats[((size_t)(a.stats_rep > 1 ? (blockIdx.x & (a.stats_rep - 1)) : 0) * a.Cout + co) * 5 + q], (double)tsum);
             }
         }
     }
@@ -341,7 +361,7 @@ __global__ void pack_ctconv_wino_kernel(const float* __restrict__ w_re, const fl
     }
 }
 
-template <int PH, int WM, int WN, int CIK>
+template <int PH, int WM, int WN, int CIK, bool STATS>
 int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
     static_assert(WCIK % CIK == 0, "a K chunk never straddles the pack granularity (nor, with it, the two sources)");
     constexpr int TR = PH == 0 ? 4 : 3;
@@ -355,7 +375,7 @@ int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
     b.mblocks = (a.cotiles + WM - 1) / WM;
     const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = ctconv_wino_kernel<PH, WM, WN, CIK, NBUF>;
+    auto k = ctconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS>;
     // more than half a CU's LDS: one workgroup per CU (the kernel is built for one: 192 / 144 accumulator registers)
     const size_t smem_req = smem > 84 * 1024 ? smem : 84 * 1024;
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req) != hipSuccess) return IDV_ELAUNCH;
@@ -366,8 +386,12 @@ int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
 // even rows, then odd rows: two launches per layer (the second reads the same raw rows from the L2 / Infinity Cache)
 template <int WM, int WN, int CIK>
 int launch_wino(const WinoArgs& a, hipStream_t st) {
-    if (int rc = launch_wino_ph<0, WM, WN, CIK>(a, st)) return rc;
-    return launch_wino_ph<1, WM, WN, CIK>(a, st);
+    if (a.stats) {
+        if (int rc = launch_wino_ph<0, WM, WN, CIK, true>(a, st)) return rc;
+        return launch_wino_ph<1, WM, WN, CIK, true>(a, st);
+    }
+    if (int rc = launch_wino_ph<0, WM, WN, CIK, false>(a, st)) return rc;
+    return launch_wino_ph<1, WM, WN, CIK, false>(a, st);
 }
 
 const bool USE_WINO = [] { const char* e = getenv("IDV_WINO"); return !e || e[0] != '0'; }();
@@ -406,14 +430,16 @@ extern "C" int idv_pack_ctconv_wino(const float* w_re, const float* w_im, int Co
     return idv_launch_status();
 }
 
-// idv_cconv2d_gauss_fwd (transposed = 1, no statistics, x1_div == 1) on the Winograd kernel: same result up to the rounding of
+// idv_cconv2d_gauss_fwd (transposed = 1, x1_div == 1; statistics as there) on the Winograd kernel: same result up to the rounding of
 // the transforms.  wfrag from idv_pack_ctconv_wino, epi / has_fold from idv_pack_cconv_gauss.  Requires 16-byte aligned sources
 // with Jp % 4 == 0 and, with a second source, the same pitch (the callers' planar buffers are).  Reference:
 // model/complex_progress.py:222-279 (+ :161-209 and pvae_module.py:82 for the epilogue).
 extern "C" int idv_ctconv2d_wino_fwd(const float* x0, int C0, const float* x1, int C1, const float* wfrag, const float* epi, int has_fold,
-                                     const float* prelu_slope, float* out, int tshift, int Cout, int Fin, int B, int Tp, int Jp,
-                                     int t_valid_out, const float* addend, int addend_div, int addend_Jp, void* stream) {
+                                     const float* prelu_slope, float* out, double* stats, double* stats_work, int stats_rep, int tshift,
+                                     int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, const float* addend, int addend_div,
+                                     int addend_Jp, void* stream) {
     if (!x0 || !wfrag || !epi || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    if (stats && stats_work && (stats_rep < 2 || (stats_rep & (stats_rep - 1)))) return IDV_EINVAL;
     if (addend && (addend_div < 1 || B % addend_div || addend_Jp < (B / addend_div) * Tp)) return IDV_EINVAL;
     if (C1 > 0 && !x1) return IDV_EINVAL;
     if (tshift != 0 && tshift != -1) return IDV_EINVAL;
@@ -430,9 +456,14 @@ extern "C" int idv_ctconv2d_wino_fwd(const float* x0, int C0, const float* x1, i
     if (Jp < a.J) return IDV_EINVAL;
     if ((long long)WCIK * Fin * (long long)Jp >= 0xffffffffLL) return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    a.stats = stats;
+    if (stats && stats_work) { a.stats = stats_work; a.stats_rep = stats_rep; }       // replicated sums, folded afterwards (common.hpp)
+    int rc;
     switch (idv_ctconv_wino_config(C0 + C1, Cout)) {
-        case 441: return launch_wino<4, 1, 4>(a, st);
-        case 422: return launch_wino<2, 2, 4>(a, st);
-        default: return launch_wino<1, 4, 4>(a, st);
+        case 441: rc = launch_wino<4, 1, 4>(a, st); break;
+        case 422: rc = launch_wino<2, 2, 4>(a, st); break;
+        default: rc = launch_wino<1, 4, 4>(a, st); break;
     }
+    if (rc || !(stats && stats_work)) return rc;
+    return idv_launch_stats_collapse(stats_work, stats_rep, Cout * 5, stats, st);
 }

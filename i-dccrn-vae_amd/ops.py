@@ -503,15 +503,17 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
             ev1.record()
             LAUNCH_LOG.append((cfg, macs, ev0, ev1))
         return out
-    if (gauss is not None and transposed and WINO and len(gauss) > 3 and gauss[3] is not None and stats is None and skip_div == 1
+    if (gauss is not None and transposed and WINO and len(gauss) > 3 and gauss[3] is not None and skip_div == 1
             and (skip is None or skip.Jp == x.Jp) and x.Jp % 4 == 0
             and L.lib().idv_ctconv_wino_supported(i(x.C), i(c1), i(cout), i(x.F))):
         # fp32 transposed conv: Winograd-transformed frequency taps on top of the three products (csrc/cgemm_wino.hip)
         if LAUNCH_LOG is not None:
             cfg = WINO_CFG + L.lib().idv_ctconv_wino_config(i(x.C + c1), i(cout))
+        swork = _stats_work(stats, cout)
         call("idv_ctconv2d_wino_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1), p(gauss[3]), p(gauss[1]),
-             i(gauss[2]), p(slope), out.ptr(), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out),
-             addend.ptr() if addend is not None else p(None), i(addend_div), i(addend.Jp if addend is not None else 0), stream_ptr())
+             i(gauss[2]), p(slope), out.ptr(), p(stats), p(swork), i(STATS_REP), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp),
+             i(t_out), addend.ptr() if addend is not None else p(None), i(addend_div), i(addend.Jp if addend is not None else 0),
+             stream_ptr())
     elif gauss is not None:
         # fp32: three real products per complex product (csrc/cgemm_gauss.hip); gauss = (wfrag3, epi, has_fold[, wino fragments])
         if LAUNCH_LOG is not None:
@@ -956,7 +958,14 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
         if wfrag_bf16 is not None:
             cfg = -(1000000 + L.lib().idv_cconv_bf16_config(i(1 if adj_transposed else 0), i(cout_adj), i(dy.F)))
         ev0.record()
-    if gauss is not None and wfrag_bf16 is None:
+    if (gauss is not None and wfrag_bf16 is None and adj_transposed and WINO and len(gauss) > 3 and gauss[3] is not None
+            and dy.Jp % 4 == 0 and L.lib().idv_ctconv_wino_supported(i(dy.C), i(0), i(cout_adj), i(dy.F))):
+        # data gradient of a conv = a transposed conv: Winograd form (csrc/cgemm_wino.hip)
+        if LAUNCH_LOG is not None:
+            cfg = WINO_CFG + L.lib().idv_ctconv_wino_config(i(dy.C), i(cout_adj))
+        call("idv_ctconv2d_wino_fwd", dy.ptr(), i(dy.C), p(None), i(0), p(gauss[3]), p(gauss[1]), i(0), p(None), out.ptr(), p(None), p(None),
+             i(0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), p(None), i(1), i(0), stream_ptr())
+    elif gauss is not None and wfrag_bf16 is None:
         if LAUNCH_LOG is not None:
             cfg = L.lib().idv_cconv_gauss_config(i(1 if adj_transposed else 0), i(dy.C), i(cout_adj), i(dy.F))
         call("idv_cconv2d_gauss_fwd", dy.ptr(), i(dy.C), p(None), i(0), i(0), i(1), p(gauss[0]), p(gauss[1]), i(0), p(None),

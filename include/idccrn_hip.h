@@ -582,16 +582,17 @@ int idv_bucket_adam(const long long* ptable, const long long* gtable, const floa
  * pair of input rows (F(2,3) on the even, F(2,2) on the odd frequency taps) on top of the three-product complex form of
  * idv_cconv2d_gauss_fwd; same result up to the rounding of the transforms.  idv_pack_ctconv_wino: weights as idv_pack_cconv_gauss
  * (transposed / conj conventions), wfrag of idv_ctconv_wino_wfrag_floats(Cout, cin_used) floats; the epilogue table (epi,
- * has_fold) is idv_pack_cconv_gauss's.  idv_ctconv2d_wino_fwd: arguments as idv_cconv2d_gauss_fwd with transposed = 1, no
- * statistics, x1_div = 1 and both sources at pitch Jp (Jp % 4 == 0, 16-byte aligned).  IDV_WINO=0 turns it off. */
+ * has_fold) is idv_pack_cconv_gauss's.  idv_ctconv2d_wino_fwd: arguments as idv_cconv2d_gauss_fwd with transposed = 1,
+ * x1_div = 1 and both sources at pitch Jp (Jp % 4 == 0, 16-byte aligned).  IDV_WINO=0 turns it off. */
 int idv_ctconv_wino_supported(int C0, int C1, int Cout, int Fin);
 long long idv_ctconv_wino_wfrag_floats(int Cout, int cin_used);
 int idv_ctconv_wino_config(int Cin, int Cout);
 int idv_pack_ctconv_wino(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used, int transposed, int conj,
                          float* wfrag, void* stream);
 int idv_ctconv2d_wino_fwd(const float* x0, int C0, const float* x1, int C1, const float* wfrag, const float* epi, int has_fold,
-                          const float* prelu_slope, float* out, int tshift, int Cout, int Fin, int B, int Tp, int Jp,
-                          int t_valid_out, const float* addend, int addend_div, int addend_Jp, void* stream);
+                          const float* prelu_slope, float* out, double* stats, double* stats_work, int stats_rep, int tshift,
+                          int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, const float* addend, int addend_div,
+                          int addend_Jp, void* stream);
 
 #ifdef __cplusplus
 }
