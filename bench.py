@@ -374,6 +374,10 @@ def kernel_name(cfg_id):
         return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
     if cfg_id == 1000001:
         return "void (anonymous namespace)::ctconv_c1_f32_kernel<false>(CgemmArgs, int)"
+    if 4000000 <= cfg_id < 5000000:       # ops.WINO_CFG + idv_ctconv_wino_config digits WM WN CIK: the two phase kernels of a layer
+        d = str(cfg_id - 4000000)
+        return (f"void (anonymous namespace)::ctconv_wino_kernel<0, {d[0]}, {d[1]}, {d[2]}, 3, false, 1, 0> + "
+                f"<1, {d[0]}, {d[1]}, {d[2]}, 3, false, 2, 8>((anonymous namespace)::WinoArgs)")
     if 3000000 <= cfg_id < 4000000:       # idv_cconv_gauss_config digits 3 MODE WM WN FO_T JC_W OCC
         d = str(cfg_id)
         occ = int(d[6])
@@ -441,6 +445,15 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
         "per_kernel": {kernel_name(k): {"tflops": round(2 * v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / steps * 1e3, 3)}
                        for k, v in sorted(groups.items())},
     }
+    if 4000000 <= dom < 5000000:
+        # Winograd-transformed frequency taps on top of the three complex products (cgemm_wino.hip): 7 of 10 real products per pair
+        # of input rows x 3 of 4 per complex product; an odd row count pads the last pair (counted as executed work it is not)
+        r["executed"] = round(0.525 * ach, 3)
+        r["frac_executed"] = round(0.525 * ach / peak, 4)
+        r["peak_note"] = ("dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32); achieved counts ALGORITHMIC flops (the reference's 4 real "
+                          "convolutions x 10 taps per complex transposed convolution, SURVEY 8(d)); the kernels execute 3 real products "
+                          "(Gauss) x 7 of 10 frequency-tap products (Winograd F(2,3) + F(2,2)): `executed` = 0.525 x achieved, "
+                          "excluding the padding row of an odd row count")
     if 3000000 <= dom < 4000000 or dom == -95:
         # three real products per complex product (Gauss, cgemm_gauss.hip): `achieved` counts the reference's 4 real convolutions
         r["executed"] = round(0.75 * ach, 3)

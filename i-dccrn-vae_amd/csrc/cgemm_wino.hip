@@ -35,7 +35,7 @@ struct WinoArgs {
     int C0, C1;
     int Fin, Fout;
     int J, Jp, Tp;
-    const float* wfrag;   // [phase 2][cotiles][units = Cin_pad * 3][64][4]: unit (ci, p), the phase's 4 / 3 (+ pad) transformed taps
+    const float* wfrag;   // [phase 2][cotiles][units = Cin_pad * 3][4][64]: unit (ci, p), the phase's 4 / 3 (+ pad) transformed taps
     int UN;               // units per co tile as packed (Cin rounded up to the pack granularity, x 3)
     const float* epi;     // as cgemm_gauss: [cotiles * 32][8]
     int has_fold;
@@ -50,7 +50,7 @@ struct WinoArgs {
     int jtiles, ftiles, mblocks;
 };
 
-constexpr int WCIK = 4;          // pack granularity in complex input channels (= cgemm_gauss's: shared `supported` rule); the kernel's K
+constexpr int WCIK = 8;          // pack granularity in complex input channels (= cgemm_gauss's: shared `supported` rule); the kernel's K
                                  // chunk CIK divides it (2: the weight ring of a chunk is 48 registers beside 336 accumulator registers)
 // transformed row tq = A + cb B of the raw rows d0..d3 (patch rows m0 - 1 .. m0 + 2); product q pairs tap q with row q
 //   PH 0 (even rows):  d0 - d2,  d1 + d2,  d2 - d1,  d1 - d3     taps  W4, (W4 + W2 + W0)/2, (W4 - W2 + W0)/2, W0
@@ -59,8 +59,9 @@ template <int PH> __device__ __forceinline__ int wino_ra(int tq) { return PH == 
 template <int PH> __device__ __forceinline__ int wino_rb(int tq) { return PH == 0 ? (tq == 2 ? 1 : (tq == 3 ? 3 : 2)) : (tq == 0 ? 2 : 3); }
 template <int PH> __device__ __forceinline__ float wino_cb(int tq) { return PH == 0 ? (tq == 1 ? 1.f : -1.f) : (tq == 1 ? 0.f : -1.f); }
 
-template <int PH, int WM, int WN, int CIK, int NBUF, bool STATS>
-__global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoArgs a) {
+// OCC: workgroups per CU the kernel is built for (2: at most 256 registers); RD: depth of the weight ring in units (0: a whole chunk)
+template <int PH, int WM, int WN, int CIK, int NBUF, bool STATS, int OCC = 1, int RDP = 0>
+__global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const WinoArgs a) {
     constexpr int NT = WM * WN * 64;
     constexpr int TR = PH == 0 ? 4 : 3;           // transformed patch rows per (channel, plane) = products per (channel, plane)
     constexpr int NP = TR;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
     constexpr int NLD = (NS + NT - 1) / NT;
     constexpr int NE = CIK * 3 * TR * PS;         // patch floats per chunk
     constexpr int UNITS = CIK * 3;                // pipeline units per chunk: (channel, plane)
-    static_assert(NLD <= 4, "staging registers");
+    static_assert(NLD <= 8, "staging registers");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
     // values of its two raw rows (A, B), forms T = A + cb B for the planes x_r and x_i and s = T_r + T_i, writes three float4.
     f32x4 sar[NLD], sai[NLD], sbr[NLD], sbi[NLD];
     unsigned voffa[NLD], voffb[NLD];  // float offsets of the two raw slots relative to the chunk's first real plane
-    unsigned okbits = 0;              // 4 column bits (a) | 4 column bits (b) per item
+    unsigned long long okbits = 0;    // 4 column bits (a) | 4 column bits (b) per item
     unsigned ldsoff[NLD];
     float cbv[NLD];
 #pragma unroll
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
             if (oka && cok) ba |= 1u << q;
             if (okb && cok) bb |= 1u << q;
         }
-        okbits |= (ba | (bb << 4)) << (8 * i);
+        okbits |= (unsigned long long)(ba | (bb << 4)) << (8 * i);
         voffa[i] = ba ? (unsigned)((cil * a.Fin + fa) * a.Jp + jv) : 0u;      // a dead slot loads mapped memory (offset 0)
         voffb[i] = bb ? (unsigned)((cil * a.Fin + fb) * a.Jp + jv) : 0u;
         cbv[i] = wino_cb<PH>(tq);
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * NT;
-            unsigned bits = (okbits >> (8 * i)) & 255u;
+            unsigned bits = (unsigned)(okbits >> (8 * i)) & 255u;
             if (e / (TR * PS4) >= cvalid) bits = 0u;
             f32x4 vr, vi, vs;
 #pragma unroll
@@ -181,10 +182,15 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
         }
     };
 
-    // ---- weights: per unit ONE 16-byte load (the 4 / 3 taps of this phase); one register set, a unit's fragment re-loaded with
-    // its next use right after the unit's MFMAs consumed it (as cgemm_gauss, rotated by one unit)
-    const f32x4* wbase = (const f32x4*)a.wfrag + ((size_t)PH * a.cotiles + (ct_ok ? ct : 0)) * a.UN * 64 + lane;
-    f32x4 a_w[UNITS];
+    // ---- weights: per unit NP 4-byte loads per lane (one coalesced 256-byte load per tap: measured 5 % faster than one 16-byte
+    // load per lane), kept in a ring of RD units: the fragments of unit g are re-loaded with those of unit g + RD right after the
+    // NEXT unit's first MFMA (rotated by one unit so that nothing loaded right before the loop's back edge is live across it, as
+    // cgemm_gauss).  RD = a whole chunk with one workgroup per CU; with two per CU the other workgroup covers the latency.
+    constexpr int RD = RDP ? RDP : UNITS;
+    static_assert(UNITS % RD == 0, "ring slots are compile-time");
+    const float* wbase = a.wfrag + (((size_t)PH * a.cotiles + (ct_ok ? ct : 0)) * a.UN) * 4 * 64 + lane;
+    const int total_units = nchunk * UNITS;
+    float a_w[RD][NP];
 
     const int bcol = wn * 32 + (lane & 31) + (lane >> 5) + COL0 + a.tshift;
     auto load_b = [&](const float* P, int u, float (&dst)[TR]) {
@@ -194,10 +200,14 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
 
     stage_load(0);
 #pragma unroll
-    for (int u = 0; u < UNITS; ++u) a_w[u] = wbase[(size_t)u * 64];
+    for (int u = 0; u < RD; ++u)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) a_w[u][q] = wbase[(size_t)(u * 4 + q) * 64];
     stage_store(smem, 0);
 #pragma unroll
-    for (int u = 0; u < UNITS; ++u) asm volatile("" : "+v"(a_w[u]));
+    for (int u = 0; u < RD; ++u)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(a_w[u][q]));
     __syncthreads();
 
     constexpr int UMID = UNITS / 2;
@@ -209,14 +219,12 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
         const int inext = (ibuf + 1 == NBUF) ? 0 : ibuf + 1;
         float* Pn = smem + inext * NE;
         const int nxt = (chunk + 1 < nchunk) ? chunk + 1 : chunk;
-        const f32x4* wnx = wbase + (size_t)nxt * UNITS * 64;
-        const f32x4* wcu = wbase + (size_t)chunk * UNITS * 64;
         if (NBUF == 2) load_b(P, 0, b_cur);
 #pragma unroll
         for (int u = 0; u < UNITS; ++u) {
             const int p3 = u % 3;
             // product q = tap q x transformed row q
-            acc[0][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u][0], b_cur[0], acc[0][p3], 0, 0, 0);
+            acc[0][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][0], b_cur[0], acc[0][p3], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (NBUF == 3 && u == UNITS - 1) __syncthreads();
             if (u + 1 < UNITS)
@@ -226,14 +234,18 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
             __builtin_amdgcn_sched_barrier(0);
             if (u == 0) stage_load(nxt);
             if (u == (NBUF == 3 ? UMID : UNITS - 1)) stage_store(Pn, nxt);
-            acc[1][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u][1], b_cur[1], acc[1][p3], 0, 0, 0);
-            acc[2][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u][2], b_cur[2], acc[2][p3], 0, 0, 0);
-            if (NP == 4) acc[NP - 1][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u][3], b_cur[NP - 1], acc[NP - 1][p3], 0, 0, 0);
+            acc[1][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][1], b_cur[1], acc[1][p3], 0, 0, 0);
+            acc[2][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][2], b_cur[2], acc[2][p3], 0, 0, 0);
+            if (NP == 4) acc[NP - 1][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][NP - 1], b_cur[NP - 1], acc[NP - 1][p3], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (u == 0)
-                a_w[UNITS - 1] = wcu[(size_t)(UNITS - 1) * 64];
-            else
-                a_w[u - 1] = wnx[(size_t)(u - 1) * 64];
+            {
+                // the PREVIOUS unit's slot is free: fetch unit (g - 1) + RD into it (clamped at the end of K: unused re-fetch)
+                int gl = chunk * UNITS + u - 1 + RD;
+                gl = gl < total_units ? gl : total_units - 1;
+                const float* ws = wbase + (size_t)gl * 4 * 64;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a_w[(u + RD - 1) % RD][q] = ws[q * 64];
+            }
             if (u + 1 < UNITS || NBUF == 3) {
 #pragma unroll
                 for (int tq = 0; tq < TR; ++tq) b_cur[tq] = b_nxt[tq];
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void ctconv_wino_kernel(const WinoA
     }
 }
 
-// fragment element (phase, ct, unit = ci * 3 + p, lane, q): tap q of the phase's transformed taps, lane = kt * 32 + col supplies
+// fragment element (phase, ct, unit = ci * 3 + p, q, lane): tap q of the phase's transformed taps, lane = kt * 32 + col supplies
 // co = ct * 32 + col.  Index conventions (transposed / conj, kt) as pack_cconv_gauss_kernel.
 __global__ void pack_ctconv_wino_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im, int Cout, int Cin_total,
                                         int Cin_used, int transposed, int conj, int UN, int cotiles, float* __restrict__ wfrag) {
@@ -345,7 +357,7 @@ __global__ void pack_ctconv_wino_kernel(const float* __restrict__ w_re, const fl
                 W[kf] = p3 == 0 ? wr : (p3 == 1 ? wi - wr : wr + wi);
             }
         }
-        f32x4 o;
+        float o[4];
         if (ph == 0) {
             o[0] = W[4];
             o[1] = 0.5f * (W[4] + W[2] + W[0]);
@@ -357,50 +369,61 @@ __global__ void pack_ctconv_wino_kernel(const float* __restrict__ w_re, const fl
             o[2] = W[1];
             o[3] = 0.f;
         }
-        *(f32x4*)(wfrag + idx * 4) = o;
+        float* dst = wfrag + ((idx >> 6) * 4) * 64 + lane;          // [phase][ct][unit][q][lane]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q * 64] = o[q];
     }
 }
 
-template <int PH, int WM, int WN, int CIK, bool STATS>
+template <int PH, int WM, int WN, int CIK, bool STATS, int OCC = 1, int RD = 0>
 int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
     static_assert(WCIK % CIK == 0, "a K chunk never straddles the pack granularity (nor, with it, the two sources)");
     constexpr int TR = PH == 0 ? 4 : 3;
     constexpr int JT = 32 * WN;
     constexpr int NE = CIK * 3 * TR * (JT + 8);
-    constexpr int NBUF = (3 * NE * sizeof(float) <= 156 * 1024) ? 3 : 2;
+    constexpr int NBUF = (3 * NE * sizeof(float) * OCC <= 156 * 1024) ? 3 : 2;
     constexpr size_t smem = NBUF * NE * sizeof(float);
+    static_assert(smem * OCC <= 160 * 1024, "the patch buffers of OCC workgroups must fit the 160 KB of LDS");
     WinoArgs b = a;
     b.jtiles = (a.J + JT - 1) / JT;
     b.ftiles = (a.Fin + 1) / 2;
     b.mblocks = (a.cotiles + WM - 1) / WM;
     const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = ctconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS>;
-    // more than half a CU's LDS: one workgroup per CU (the kernel is built for one: 192 / 144 accumulator registers)
-    const size_t smem_req = smem > 84 * 1024 ? smem : 84 * 1024;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req) != hipSuccess) return IDV_ELAUNCH;
+    auto k = ctconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS, OCC, RD>;
+    // OCC 1: more than half a CU's LDS, i.e. one workgroup per CU whatever the register count says
+    const size_t smem_req = OCC == 1 ? (smem > 84 * 1024 ? smem : 84 * 1024) : smem;
+    if (smem_req > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req) != hipSuccess) return IDV_ELAUNCH;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(WM * WN * 64), smem_req, st, b);
     return idv_launch_status();
 }
 
-// even rows, then odd rows: two launches per layer (the second reads the same raw rows from the L2 / Infinity Cache)
+// even rows, then odd rows: two launches per layer (the second reads the same raw rows from the L2 / Infinity Cache).
+// IDV_WINO_PH1 (experiments): 0 = the odd-row phase as the even one (one workgroup per CU, ring = a chunk); default: two
+// workgroups per CU with a ring of 8 units (9 accumulator tiles = 144 registers leave room for it)
+template <int WM, int WN, int CIK, bool STATS>
+int launch_wino_s(const WinoArgs& a, hipStream_t st) {
+    static const int ph1 = [] { const char* e = getenv("IDV_WINO_PH1"); return e ? atoi(e) : 1; }();
+    if (int rc = launch_wino_ph<0, WM, WN, CIK, STATS>(a, st)) return rc;
+    if (ph1 == 0) return launch_wino_ph<1, WM, WN, CIK, STATS>(a, st);
+    return launch_wino_ph<1, WM, WN, CIK, STATS, 2, (CIK * 3) % 8 == 0 ? 8 : 6>(a, st);
+}
 template <int WM, int WN, int CIK>
 int launch_wino(const WinoArgs& a, hipStream_t st) {
-    if (a.stats) {
-        if (int rc = launch_wino_ph<0, WM, WN, CIK, true>(a, st)) return rc;
-        return launch_wino_ph<1, WM, WN, CIK, true>(a, st);
-    }
-    if (int rc = launch_wino_ph<0, WM, WN, CIK, false>(a, st)) return rc;
-    return launch_wino_ph<1, WM, WN, CIK, false>(a, st);
+    return a.stats ? launch_wino_s<WM, WN, CIK, true>(a, st) : launch_wino_s<WM, WN, CIK, false>(a, st);
 }
 
 const bool USE_WINO = [] { const char* e = getenv("IDV_WINO"); return !e || e[0] != '0'; }();
 
 }  // namespace
 
-// 1 if the Winograd form serves this transposed-conv layer: what cgemm_gauss serves, with more than one input row
+// 1 if the Winograd form serves this transposed-conv layer: what cgemm_gauss serves, with more than one input row and more than
+// one tile of 32 complex output channels (one co tile x four column groups measured 3 % SLOWER than cgemm_gauss's two-workgroup
+// form on dec4, 128 -> 32 channels: the staging transform is then amortised over one co tile only)
 extern "C" int idv_ctconv_wino_supported(int C0, int C1, int Cout, int Fin) {
-    if (!USE_WINO || Fin < 2) return 0;
+    static const int min_cout = [] { const char* e = getenv("IDV_WINO_MIN_COUT"); return e ? atoi(e) : 33; }();
+    if (!USE_WINO || Fin < 2 || Cout < min_cout) return 0;
     return idv_cconv_gauss_supported(C0, C1, Cout);
 }
 
@@ -409,10 +432,12 @@ extern "C" long long idv_ctconv_wino_wfrag_floats(int Cout, int cin_used) {
     return 2 * cotiles * cpad * 3 * 64 * 4;               // [phase][co tile][unit][lane][4]
 }
 
-// configuration id for bench.py / profiles: 4 WM WN (e.g. 441 = four co tiles x one column group)
+// configuration id for bench.py / profiles: WM WN CIK as decimal digits (418 = four co tiles x one column group, 8 channels per
+// K chunk).  Per layer at B = 64 (tests/tools/wino_layers_probe.py, against cgemm_gauss): dec0 13.15 -> 12.97 ms, dec1 11.73 ->
+// 10.94, dec2 11.46 -> 10.09 (418); dec3 11.75 -> 10.59 (228)
 extern "C" int idv_ctconv_wino_config(int Cin, int Cout) {
     (void)Cin;
-    return Cout >= 128 ? 441 : (Cout > 32 ? 422 : 414);
+    return Cout >= 128 ? 418 : (Cout > 32 ? 228 : 144);
 }
 
 // Winograd-transformed Gauss planes of a ComplexConvTranspose2d weight (w_*: [Cin][Cout][5][2], transposed = 1) or of the adjoint
@@ -459,10 +484,18 @@ extern "C" int idv_ctconv2d_wino_fwd(const float* x0, int C0, const float* x1, i
     a.stats = stats;
     if (stats && stats_work) { a.stats = stats_work; a.stats_rep = stats_rep; }       // replicated sums, folded afterwards (common.hpp)
     int rc;
-    switch (idv_ctconv_wino_config(C0 + C1, Cout)) {
-        case 441: rc = launch_wino<4, 1, 4>(a, st); break;
-        case 422: rc = launch_wino<2, 2, 4>(a, st); break;
-        default: rc = launch_wino<1, 4, 4>(a, st); break;
+    // experiments: IDV_WINO_CFG = WM WN CIK as decimal digits (e.g. 418: four co tiles x one column group, 8 channels per chunk)
+    static const int xcfg = [] { const char* e = getenv("IDV_WINO_CFG"); return e ? atoi(e) : 0; }();
+    int cfg = xcfg ? xcfg : idv_ctconv_wino_config(C0 + C1, Cout);
+    if (C1 > 0 && C0 % (cfg % 10)) cfg = cfg / 10 * 10 + 4;          // a K chunk must not straddle the two sources (C0 % 4 == 0 holds)
+    switch (cfg) {
+        case 414: rc = launch_wino<4, 1, 4>(a, st); break;
+        case 418: rc = launch_wino<4, 1, 8>(a, st); break;
+        case 224: rc = launch_wino<2, 2, 4>(a, st); break;
+        case 228: rc = launch_wino<2, 2, 8>(a, st); break;
+        case 144: rc = launch_wino<1, 4, 4>(a, st); break;
+        case 142: rc = launch_wino<1, 4, 2>(a, st); break;
+        default: return IDV_EINVAL;
     }
     if (rc || !(stats && stats_work)) return rc;
     return idv_launch_stats_collapse(stats_work, stats_rep, Cout * 5, stats, st);
