@@ -374,10 +374,13 @@ def kernel_name(cfg_id):
         return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
     if cfg_id == 1000001:
         return "void (anonymous namespace)::ctconv_c1_f32_kernel<false>(CgemmArgs, int)"
-    if 4000000 <= cfg_id < 5000000:       # ops.WINO_CFG + idv_ctconv_wino_config digits WM WN CIK: the two phase kernels of a layer
-        d = str(cfg_id - 4000000)
-        return (f"void (anonymous namespace)::ctconv_wino_kernel<0, {d[0]}, {d[1]}, {d[2]}, 3, false, 1, 0> + "
-                f"<1, {d[0]}, {d[1]}, {d[2]}, 3, false, 2, 8>((anonymous namespace)::WinoArgs)")
+    if 4000000 <= cfg_id < 5000000:       # ops.WINO_CFG + 1000 * transposed + idv_cconv_wino_config digits WM WN CIK
+        tr, d = (cfg_id - 4000000) // 1000, str((cfg_id - 4000000) % 1000)
+        if tr:                                # the two phase kernels of a transposed-conv layer
+            return (f"void (anonymous namespace)::cconv_wino_kernel<0, {d[0]}, {d[1]}, {d[2]}, 3, false, 1, 0> + "
+                    f"<1, {d[0]}, {d[1]}, {d[2]}, 3, false, 2, 8>((anonymous namespace)::WinoArgs)")
+        return (f"void (anonymous namespace)::cconv_wino_kernel<2, {d[0]}, {d[1]}, {d[2]}, 3, false, 1, {3 * int(d[2]) // 2}>"
+                "((anonymous namespace)::WinoArgs)")
     if 3000000 <= cfg_id < 4000000:       # idv_cconv_gauss_config digits 3 MODE WM WN FO_T JC_W OCC
         d = str(cfg_id)
         occ = int(d[6])

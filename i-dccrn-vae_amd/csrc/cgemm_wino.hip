@@ -17,7 +17,15 @@
 // idv_pack_ctconv_wino, the output transform is register-local in the epilogue.  All factors are 1 or 1/2: the transforms are
 // exact in fp32 up to the rounding of the sums (measured: DESIGN.md 3.1d).
 //
-// Two kinds of workgroup tiles (template PH), because an MFMA's accumulators live in the 256 AGPRs = at most 16 tiles per wave
+// The encoder's stride-(2, 1) convolution (model/complex_progress.py:8-36) is the mirror image: with r0..r6 = x[2 fo - 2 .. 2 fo + 4]
+// the even taps (W0, W2, W4) form a 3-tap correlation over the even-offset rows (r0, r2, r4, r6), the odd taps (W1, W3) a 2-tap
+// one over (r1, r3, r5), and BOTH feed the same two outputs out[fo], out[fo + 1] -- so the seven products share FOUR accumulators
+//     A0 = (r0 - r4) W0 + (r1 - r3) W1      A1 = (r2 + r4) (W0 + W2 + W4)/2 + r3 (W1 + W3)
+//     A2 = (r4 - r2) (W0 - W2 + W4)/2       A3 = (r2 - r6) W4 + (r3 - r5) W3
+//     out[fo] = A0 + A1 + A2                out[fo + 1] = A1 - A2 - A3
+// (template PH = 2: 7 products on 7 transformed rows into 4 x 3 = 12 accumulator tiles per wave).
+//
+// Two kinds of workgroup tiles for the transposed conv (template PH = 0 / 1), because an MFMA's accumulators live in the 256 AGPRs = at most 16 tiles per wave
 // (with more, hipcc swaps the rest through the AGPRs around every MFMA): PH = 0 computes the EVEN output rows of a pair of input
 // rows (F(2,3): 4 products x 3 Gauss planes = 12 accumulator tiles per wave, 4 transformed patch rows), PH = 1 the ODD rows
 // (F(2,2): 3 x 3 = 9 tiles, 3 transformed rows).  Per wave: 32 complex output channels x 2 output rows x ONE 32-column tile.
@@ -35,7 +43,8 @@ struct WinoArgs {
     int C0, C1;
     int Fin, Fout;
     int J, Jp, Tp;
-    const float* wfrag;   // [phase 2][cotiles][units = Cin_pad * 3][4][64]: unit (ci, p), the phase's 4 / 3 (+ pad) transformed taps
+    const float* wfrag;   // transposed: [phase 2][cotiles][units = Cin_pad * 3][4][64] (the phase's 4 / 3 + pad transformed taps of unit
+                          // (ci, p)); conv: [cotiles][units][8][64] (7 taps + pad)
     int UN;               // units per co tile as packed (Cin rounded up to the pack granularity, x 3)
     const float* epi;     // as cgemm_gauss: [cotiles * 32][8]
     int has_fold;
@@ -52,19 +61,38 @@ struct WinoArgs {
 
 constexpr int WCIK = 8;          // pack granularity in complex input channels (= cgemm_gauss's: shared `supported` rule); the kernel's K
                                  // chunk CIK divides it (2: the weight ring of a chunk is 48 registers beside 336 accumulator registers)
-// transformed row tq = A + cb B of the raw rows d0..d3 (patch rows m0 - 1 .. m0 + 2); product q pairs tap q with row q
-//   PH 0 (even rows):  d0 - d2,  d1 + d2,  d2 - d1,  d1 - d3     taps  W4, (W4 + W2 + W0)/2, (W4 - W2 + W0)/2, W0
-//   PH 1 (odd rows):   d1 - d2,  d2,       d2 - d3               taps  W3, W3 + W1, W1
-template <int PH> __device__ __forceinline__ int wino_ra(int tq) { return PH == 0 ? (tq == 0 ? 0 : (tq == 2 ? 2 : 1)) : (tq == 0 ? 1 : 2); }
-template <int PH> __device__ __forceinline__ int wino_rb(int tq) { return PH == 0 ? (tq == 2 ? 1 : (tq == 3 ? 3 : 2)) : (tq == 0 ? 2 : 3); }
-template <int PH> __device__ __forceinline__ float wino_cb(int tq) { return PH == 0 ? (tq == 1 ? 1.f : -1.f) : (tq == 1 ? 0.f : -1.f); }
+// transformed row tq = A + cb B of the raw patch rows (transposed conv: d0..d3 = input rows m0 - 1 .. m0 + 2; conv: r0..r6 = input
+// rows 2 fo0 - 2 .. 2 fo0 + 4); product q pairs tap q with row q and adds into accumulator wino_acc(q)
+//   PH 0 (transposed, even rows):  d0 - d2,  d1 + d2,  d2 - d1,  d1 - d3     taps  W4, (W4 + W2 + W0)/2, (W4 - W2 + W0)/2, W0
+//   PH 1 (transposed, odd rows):   d1 - d2,  d2,       d2 - d3               taps  W3, W3 + W1, W1
+//   PH 2 (conv):  r0 - r4,  r2 + r4,  r4 - r2,  r2 - r6,  r1 - r3,  r3,  r3 - r5
+//                 taps  W0, (W0 + W2 + W4)/2, (W0 - W2 + W4)/2, W4, W1, W1 + W3, W3      accumulators 0, 1, 2, 3, 0, 1, 3
+template <int PH> __device__ __forceinline__ int wino_ra(int tq) {
+    if (PH == 0) return tq == 0 ? 0 : (tq == 2 ? 2 : 1);
+    if (PH == 1) return tq == 0 ? 1 : 2;
+    return tq == 0 ? 0 : (tq == 1 ? 2 : (tq == 2 ? 4 : (tq == 3 ? 2 : (tq == 4 ? 1 : 3))));
+}
+template <int PH> __device__ __forceinline__ int wino_rb(int tq) {
+    if (PH == 0) return tq == 2 ? 1 : (tq == 3 ? 3 : 2);
+    if (PH == 1) return tq == 0 ? 2 : 3;
+    return tq == 0 ? 4 : (tq == 1 ? 4 : (tq == 2 ? 2 : (tq == 3 ? 6 : (tq == 4 ? 3 : 5))));       // tq == 5: unused
+}
+template <int PH> __device__ __forceinline__ float wino_cb(int tq) {
+    if (PH == 0) return tq == 1 ? 1.f : -1.f;
+    if (PH == 1) return tq == 1 ? 0.f : -1.f;
+    return tq == 1 ? 1.f : (tq == 5 ? 0.f : -1.f);
+}
+template <int PH> constexpr int wino_tr() { return PH == 0 ? 4 : (PH == 1 ? 3 : 7); }
+template <int PH> constexpr int wino_nacc() { return PH == 1 ? 3 : 4; }
+template <int PH> constexpr int wino_slots() { return PH == 2 ? 8 : 4; }          // weight slots per unit in the packed buffer
+constexpr int wino_acc2(int q) { return q < 4 ? q : (q == 4 ? 0 : (q == 5 ? 1 : 3)); }
 
 // OCC: workgroups per CU the kernel is built for (2: at most 256 registers); RD: depth of the weight ring in units (0: a whole chunk)
 template <int PH, int WM, int WN, int CIK, int NBUF, bool STATS, int OCC = 1, int RDP = 0>
-__global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const WinoArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, OCC) void cconv_wino_kernel(const WinoArgs a) {
     constexpr int NT = WM * WN * 64;
-    constexpr int TR = PH == 0 ? 4 : 3;           // transformed patch rows per (channel, plane) = products per (channel, plane)
-    constexpr int NP = TR;
+    constexpr int TR = wino_tr<PH>();             // transformed patch rows per (channel, plane) = products per (channel, plane)
+    constexpr int NP = TR, NACC = wino_nacc<PH>(), SL = wino_slots<PH>();
     constexpr int JT = 32 * WN;
     constexpr int PS = JT + 8;                    // patch row: the 16-byte aligned span j0-4 .. j0+JT+3
     constexpr int COL0 = 4;
@@ -96,14 +124,15 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const Win
     const int j0 = jt * JT;
     const int ct = mblk * WM + wm;
     const bool ct_ok = ct < a.cotiles;
-    const int m0 = 2 * ft;                        // first input row of the tile; raw patch rows m0 - 1 .. m0 + 2
+    const int m0 = 2 * ft;                        // transposed: first input row of the tile (raw patch rows m0 - 1 .. m0 + 2);
+    const int rbase = PH == 2 ? 2 * m0 - 2 : m0 - 1;      // conv: first OUTPUT row (raw patch rows 2 m0 - 2 .. 2 m0 + 4)
 
     const int Cin = a.C0 + a.C1;
     const int nchunk = (Cin + CIK - 1) / CIK;
 
-    f32x16 acc[NP][3];
+    f32x16 acc[NACC][3];
 #pragma unroll
-    for (int w = 0; w < NP; ++w)
+    for (int w = 0; w < NACC; ++w)
 #pragma unroll
         for (int p3 = 0; p3 < 3; ++p3)
 #pragma unroll
@@ -121,7 +150,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const Win
         const int e = tid + i * NT;
         const int row = e / PS4, c4 = e - row * PS4;
         const int cil = row / TR, tq = row - cil * TR;
-        const int fa = m0 - 1 + wino_ra<PH>(tq), fb = m0 - 1 + wino_rb<PH>(tq);
+        const int fa = rbase + wino_ra<PH>(tq), fb = rbase + wino_rb<PH>(tq);
         const int jv = j0 - 4 + 4 * c4;
         const bool oka = (e < NS) && fa >= 0 && fa < a.Fin;
         const bool okb = (e < NS) && wino_cb<PH>(tq) != 0.f && fb >= 0 && fb < a.Fin;
@@ -188,7 +217,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const Win
     // cgemm_gauss).  RD = a whole chunk with one workgroup per CU; with two per CU the other workgroup covers the latency.
     constexpr int RD = RDP ? RDP : UNITS;
     static_assert(UNITS % RD == 0, "ring slots are compile-time");
-    const float* wbase = a.wfrag + (((size_t)PH * a.cotiles + (ct_ok ? ct : 0)) * a.UN) * 4 * 64 + lane;
+    const float* wbase = a.wfrag + (((size_t)(PH == 1 ? a.cotiles : 0) + (ct_ok ? ct : 0)) * a.UN) * SL * 64 + lane;
     const int total_units = nchunk * UNITS;
     float a_w[RD][NP];
 
@@ -202,7 +231,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const Win
 #pragma unroll
     for (int u = 0; u < RD; ++u)
 #pragma unroll
-        for (int q = 0; q < NP; ++q) a_w[u][q] = wbase[(size_t)(u * 4 + q) * 64];
+        for (int q = 0; q < NP; ++q) a_w[u][q] = wbase[(size_t)(u * SL + q) * 64];
     stage_store(smem, 0);
 #pragma unroll
     for (int u = 0; u < RD; ++u)
@@ -223,7 +252,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const Win
 #pragma unroll
         for (int u = 0; u < UNITS; ++u) {
             const int p3 = u % 3;
-            // product q = tap q x transformed row q
+            // product q = tap q x transformed row q -> accumulator q (conv: 0, 1, 2, 3, 0, 1, 3)
             acc[0][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][0], b_cur[0], acc[0][p3], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (NBUF == 3 && u == UNITS - 1) __syncthreads();
@@ -234,15 +263,19 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const Win
             __builtin_amdgcn_sched_barrier(0);
             if (u == 0) stage_load(nxt);
             if (u == (NBUF == 3 ? UMID : UNITS - 1)) stage_store(Pn, nxt);
-            acc[1][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][1], b_cur[1], acc[1][p3], 0, 0, 0);
-            acc[2][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][2], b_cur[2], acc[2][p3], 0, 0, 0);
-            if (NP == 4) acc[NP - 1][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][NP - 1], b_cur[NP - 1], acc[NP - 1][p3], 0, 0, 0);
+#pragma unroll
+            for (int q = 1; q < NP; ++q) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int ai = PH == 2 ? wino_acc2(q) : q;
+                acc[ai][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][q], b_cur[q], acc[ai][p3], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             {
                 // the PREVIOUS unit's slot is free: fetch unit (g - 1) + RD into it (clamped at the end of K: unused re-fetch)
                 int gl = chunk * UNITS + u - 1 + RD;
                 gl = gl < total_units ? gl : total_units - 1;
-                const float* ws = wbase + (size_t)gl * 4 * 64;
+                const float* ws = wbase + (size_t)gl * SL * 64;
 #pragma unroll
                 for (int q = 0; q < NP; ++q) a_w[(u + RD - 1) % RD][q] = ws[q * 64];
             }
@@ -275,8 +308,8 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const Win
         float t[2][3];                       // this phase's two output rows x Gauss products
 #pragma unroll
         for (int p3 = 0; p3 < 3; ++p3) {
-            if (PH == 0) {
-                const float M1 = acc[0][p3][r], M2 = acc[1][p3][r], M3 = acc[2][p3][r], M4 = acc[NP - 1][p3][r];
+            if (PH != 1) {
+                const float M1 = acc[0][p3][r], M2 = acc[1][p3][r], M3 = acc[2][p3][r], M4 = acc[NACC - 1][p3][r];
                 t[0][p3] = M1 + M2 + M3;
                 t[1][p3] = M2 - M3 - M4;
             } else {
@@ -287,7 +320,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const Win
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            const int fo = 2 * m0 + PH + 2 * rt;
+            const int fo = PH == 2 ? m0 + rt : 2 * m0 + PH + 2 * rt;
             if (fo >= a.Fout) continue;
             float re = t[rt][0] - t[rt][2], im = t[rt][0] + t[rt][1];
             if (a.add && cok && inb) {
@@ -334,16 +367,24 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void ctconv_wino_kernel(const Win
 }
 
 // fragment element (phase, ct, unit = ci * 3 + p, q, lane): tap q of the phase's transformed taps, lane = kt * 32 + col supplies
-// co = ct * 32 + col.  Index conventions (transposed / conj, kt) as pack_cconv_gauss_kernel.
-__global__ void pack_ctconv_wino_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im, int Cout, int Cin_total,
-                                        int Cin_used, int transposed, int conj, int UN, int cotiles, float* __restrict__ wfrag) {
-    const long long n = 2LL * cotiles * UN * 64;                  // one thread per (phase, ct, unit, lane): 4 floats
+// co = ct * 32 + col.  Index conventions (transposed / conj, kt) as pack_cconv_gauss_kernel.  transposed operator: two phases of
+// 4 slots per unit (even-row taps | odd-row taps + padding); conv operator: one block of 8 slots per unit (7 taps + padding).
+__global__ void pack_cconv_wino_kernel(const float* __restrict__ w_re, const float* __restrict__ w_im, int Cout, int Cin_total,
+                                       int Cin_used, int transposed, int conj, int UN, int cotiles, float* __restrict__ wfrag) {
+    const long long n = 2LL * cotiles * UN * 64;                  // one thread per (half, ct, unit, lane): 4 floats
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         long long t = idx >> 6;
-        const int unit = (int)(t % UN); t /= UN;
-        const int ct = (int)(t % cotiles);
-        const int ph = (int)(t / cotiles);
+        int unit, ct, hf;
+        if (transposed) {                                          // [phase][ct][unit]
+            unit = (int)(t % UN); t /= UN;
+            ct = (int)(t % cotiles);
+            hf = (int)(t / cotiles);
+        } else {                                                   // [ct][unit][half]
+            hf = (int)(t & 1); t >>= 1;
+            unit = (int)(t % UN);
+            ct = (int)(t / UN);
+        }
         const int h = lane >> 5, co = ct * 32 + (lane & 31);
         const int ci = unit / 3, p3 = unit % 3;
         float W[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -358,18 +399,20 @@ __global__ void pack_ctconv_wino_kernel(const float* __restrict__ w_re, const fl
             }
         }
         float o[4];
-        if (ph == 0) {
-            o[0] = W[4];
-            o[1] = 0.5f * (W[4] + W[2] + W[0]);
-            o[2] = 0.5f * (W[4] - W[2] + W[0]);
-            o[3] = W[0];
+        if (transposed) {
+            if (hf == 0) {
+                o[0] = W[4]; o[1] = 0.5f * (W[4] + W[2] + W[0]); o[2] = 0.5f * (W[4] - W[2] + W[0]); o[3] = W[0];
+            } else {
+                o[0] = W[3]; o[1] = W[3] + W[1]; o[2] = W[1]; o[3] = 0.f;
+            }
         } else {
-            o[0] = W[3];
-            o[1] = W[3] + W[1];
-            o[2] = W[1];
-            o[3] = 0.f;
+            if (hf == 0) {
+                o[0] = W[0]; o[1] = 0.5f * (W[0] + W[2] + W[4]); o[2] = 0.5f * (W[0] - W[2] + W[4]); o[3] = W[4];
+            } else {
+                o[0] = W[1]; o[1] = W[1] + W[3]; o[2] = W[3]; o[3] = 0.f;
+            }
         }
-        float* dst = wfrag + ((idx >> 6) * 4) * 64 + lane;          // [phase][ct][unit][q][lane]
+        float* dst = wfrag + ((idx >> 6) * 4) * 64 + lane;          // 4 slots of 64 lanes per (.., half)
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q * 64] = o[q];
     }
@@ -378,7 +421,7 @@ __global__ void pack_ctconv_wino_kernel(const float* __restrict__ w_re, const fl
 template <int PH, int WM, int WN, int CIK, bool STATS, int OCC = 1, int RD = 0>
 int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
     static_assert(WCIK % CIK == 0, "a K chunk never straddles the pack granularity (nor, with it, the two sources)");
-    constexpr int TR = PH == 0 ? 4 : 3;
+    constexpr int TR = wino_tr<PH>();
     constexpr int JT = 32 * WN;
     constexpr int NE = CIK * 3 * TR * (JT + 8);
     constexpr int NBUF = (3 * NE * sizeof(float) * OCC <= 156 * 1024) ? 3 : 2;
@@ -386,11 +429,11 @@ int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
     static_assert(smem * OCC <= 160 * 1024, "the patch buffers of OCC workgroups must fit the 160 KB of LDS");
     WinoArgs b = a;
     b.jtiles = (a.J + JT - 1) / JT;
-    b.ftiles = (a.Fin + 1) / 2;
+    b.ftiles = ((PH == 2 ? a.Fout : a.Fin) + 1) / 2;
     b.mblocks = (a.cotiles + WM - 1) / WM;
     const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = ctconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS, OCC, RD>;
+    auto k = cconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS, OCC, RD>;
     // OCC 1: more than half a CU's LDS, i.e. one workgroup per CU whatever the register count says
     const size_t smem_req = OCC == 1 ? (smem > 84 * 1024 ? smem : 84 * 1024) : smem;
     if (smem_req > 64 * 1024 &&
@@ -399,80 +442,89 @@ int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
     return idv_launch_status();
 }
 
-// even rows, then odd rows: two launches per layer (the second reads the same raw rows from the L2 / Infinity Cache).
-// IDV_WINO_PH1 (experiments): 0 = the odd-row phase as the even one (one workgroup per CU, ring = a chunk); default: two
-// workgroups per CU with a ring of 8 units (9 accumulator tiles = 144 registers leave room for it)
+// transposed conv: even rows, then odd rows: two launches per layer (the second reads the same raw rows from the L2 / Infinity
+// Cache).  IDV_WINO_PH1 (experiments): 0 = the odd-row phase as the even one (one workgroup per CU, ring = a chunk); default: two
+// workgroups per CU with a ring of 8 units (9 accumulator tiles = 144 registers leave room for it).  conv: one launch, the weight
+// ring half a chunk deep (7 fragments per unit).
 template <int WM, int WN, int CIK, bool STATS>
-int launch_wino_s(const WinoArgs& a, hipStream_t st) {
+int launch_wino_s(const WinoArgs& a, int transposed, hipStream_t st) {
+    if (!transposed) return launch_wino_ph<2, WM, WN, CIK, STATS, 1, (CIK * 3) / 2>(a, st);
     static const int ph1 = [] { const char* e = getenv("IDV_WINO_PH1"); return e ? atoi(e) : 1; }();
     if (int rc = launch_wino_ph<0, WM, WN, CIK, STATS>(a, st)) return rc;
     if (ph1 == 0) return launch_wino_ph<1, WM, WN, CIK, STATS>(a, st);
     return launch_wino_ph<1, WM, WN, CIK, STATS, 2, (CIK * 3) % 8 == 0 ? 8 : 6>(a, st);
 }
 template <int WM, int WN, int CIK>
-int launch_wino(const WinoArgs& a, hipStream_t st) {
-    return a.stats ? launch_wino_s<WM, WN, CIK, true>(a, st) : launch_wino_s<WM, WN, CIK, false>(a, st);
+int launch_wino(const WinoArgs& a, int transposed, hipStream_t st) {
+    return a.stats ? launch_wino_s<WM, WN, CIK, true>(a, transposed, st) : launch_wino_s<WM, WN, CIK, false>(a, transposed, st);
 }
 
 const bool USE_WINO = [] { const char* e = getenv("IDV_WINO"); return !e || e[0] != '0'; }();
+const bool USE_WINO_CONV = [] { const char* e = getenv("IDV_WINO_CONV"); return !e || e[0] != '0'; }();
 
 }  // namespace
 
-// 1 if the Winograd form serves this transposed-conv layer: what cgemm_gauss serves, with more than one input row and more than
-// one tile of 32 complex output channels (one co tile x four column groups measured 3 % SLOWER than cgemm_gauss's two-workgroup
-// form on dec4, 128 -> 32 channels: the staging transform is then amortised over one co tile only)
-extern "C" int idv_ctconv_wino_supported(int C0, int C1, int Cout, int Fin) {
+// 1 if the Winograd form serves this layer: what cgemm_gauss serves, where it measured faster (B = 64, tests/tools/
+// wino_layers_probe.py): transposed conv with more than one tile of 32 complex output channels (one co tile x four column groups was
+// 3 % SLOWER than cgemm_gauss's two-workgroup form on dec4, 128 -> 32: the staging transform is then amortised over one co tile
+// only) and at least two input rows; conv with >= 128 input AND output channels (enc3 5.69 -> 5.38 ms, enc4 6.08 -> 5.86, enc5
+// 6.78 -> 6.69; enc2 64 -> 128 ties, enc1 32 -> 64 loses: cgemm_gauss runs those at two workgroups per CU) and >= 2 output rows.
+extern "C" int idv_cconv_wino_supported(int transposed, int C0, int C1, int Cout, int Fin) {
     static const int min_cout = [] { const char* e = getenv("IDV_WINO_MIN_COUT"); return e ? atoi(e) : 33; }();
-    if (!USE_WINO || Fin < 2 || Cout < min_cout) return 0;
+    static const int conv_min = [] { const char* e = getenv("IDV_WINO_CONV_MINC"); return e ? atoi(e) : 128; }();
+    if (!USE_WINO || (!transposed && !USE_WINO_CONV) || Cout < min_cout) return 0;
+    if (transposed ? Fin < 2 : ((Fin - 1) / 2 + 1 < 2 || Cout < conv_min || C0 + C1 < conv_min)) return 0;
     return idv_cconv_gauss_supported(C0, C1, Cout);
 }
 
-extern "C" long long idv_ctconv_wino_wfrag_floats(int Cout, int cin_used) {
+extern "C" long long idv_cconv_wino_wfrag_floats(int transposed, int Cout, int cin_used) {
+    (void)transposed;                                     // both forms: 8 slots of 64 lanes per (co tile, unit)
     const long long cotiles = (Cout + 31) / 32, cpad = (cin_used + WCIK - 1) / WCIK * WCIK;
-    return 2 * cotiles * cpad * 3 * 64 * 4;               // [phase][co tile][unit][lane][4]
+    return cotiles * cpad * 3 * 8 * 64;
 }
 
 // configuration id for bench.py / profiles: WM WN CIK as decimal digits (418 = four co tiles x one column group, 8 channels per
 // K chunk).  Per layer at B = 64 (tests/tools/wino_layers_probe.py, against cgemm_gauss): dec0 13.15 -> 12.97 ms, dec1 11.73 ->
 // 10.94, dec2 11.46 -> 10.09 (418); dec3 11.75 -> 10.59 (228)
-extern "C" int idv_ctconv_wino_config(int Cin, int Cout) {
+extern "C" int idv_cconv_wino_config(int transposed, int Cin, int Cout) {
     (void)Cin;
+    if (!transposed) return Cout >= 128 ? 418 : 228;
     return Cout >= 128 ? 418 : (Cout > 32 ? 228 : 144);
 }
 
-// Winograd-transformed Gauss planes of a ComplexConvTranspose2d weight (w_*: [Cin][Cout][5][2], transposed = 1) or of the adjoint
-// of a ComplexConv2d (w_*: [Cout'][Cin'][5][2] read as [Cin = Cout'][..], transposed = 0, conj = 1: the data-gradient operator),
-// conventions as idv_pack_cconv_gauss.  The epilogue table is idv_pack_cconv_gauss's.
-extern "C" int idv_pack_ctconv_wino(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used, int transposed,
-                                    int conj, float* wfrag, void* stream) {
+// Winograd-transformed Gauss planes of a complex conv / transposed conv weight, conventions (transposed = the OPERATOR's mode =
+// the tensor's layout, conj for the adjoint / data-gradient operators) as idv_pack_cconv_gauss; the epilogue table is that
+// function's.  wfrag: idv_cconv_wino_wfrag_floats(transposed, Cout, Cin_used) floats.
+extern "C" int idv_pack_cconv_wino(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used, int transposed,
+                                   int conj, float* wfrag, void* stream) {
     if (!w_re || !w_im || !wfrag || Cout <= 0 || Cin_used <= 0 || Cin_used > Cin_total) return IDV_EINVAL;
     const int cotiles = (Cout + 31) / 32;
     const int UN = (Cin_used + WCIK - 1) / WCIK * WCIK * 3;
     const long long n = 2LL * cotiles * UN * 64;
     const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    hipLaunchKernelGGL(pack_ctconv_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_re, w_im, Cout, Cin_total, Cin_used,
+    hipLaunchKernelGGL(pack_cconv_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_re, w_im, Cout, Cin_total, Cin_used,
                        transposed, conj, UN, cotiles, wfrag);
     return idv_launch_status();
 }
 
-// idv_cconv2d_gauss_fwd (transposed = 1, x1_div == 1; statistics as there) on the Winograd kernel: same result up to the rounding of
-// the transforms.  wfrag from idv_pack_ctconv_wino, epi / has_fold from idv_pack_cconv_gauss.  Requires 16-byte aligned sources
-// with Jp % 4 == 0 and, with a second source, the same pitch (the callers' planar buffers are).  Reference:
-// model/complex_progress.py:222-279 (+ :161-209 and pvae_module.py:82 for the epilogue).
-extern "C" int idv_ctconv2d_wino_fwd(const float* x0, int C0, const float* x1, int C1, const float* wfrag, const float* epi, int has_fold,
-                                     const float* prelu_slope, float* out, double* stats, double* stats_work, int stats_rep, int tshift,
-                                     int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, const float* addend, int addend_div,
-                                     int addend_Jp, void* stream) {
+// idv_cconv2d_gauss_fwd (x1_div == 1; statistics as there) on the Winograd kernels: same result up to the rounding of the
+// transforms.  wfrag from idv_pack_cconv_wino, epi / has_fold from idv_pack_cconv_gauss.  Requires 16-byte aligned sources with
+// Jp % 4 == 0 and, with a second source, the same pitch (the callers' planar buffers are).  Reference:
+// model/complex_progress.py:8-36, :222-279 (+ :161-209 and pvae_module.py:58,82 for the epilogue).
+extern "C" int idv_cconv2d_wino_fwd(const float* x0, int C0, const float* x1, int C1, const float* wfrag, const float* epi, int has_fold,
+                                    const float* prelu_slope, float* out, double* stats, double* stats_work, int stats_rep,
+                                    int transposed, int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out,
+                                    const float* addend, int addend_div, int addend_Jp, void* stream) {
     if (!x0 || !wfrag || !epi || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
     if (stats && stats_work && (stats_rep < 2 || (stats_rep & (stats_rep - 1)))) return IDV_EINVAL;
     if (addend && (addend_div < 1 || B % addend_div || addend_Jp < (B / addend_div) * Tp)) return IDV_EINVAL;
     if (C1 > 0 && !x1) return IDV_EINVAL;
     if (tshift != 0 && tshift != -1) return IDV_EINVAL;
-    if (!idv_ctconv_wino_supported(C0, C1, Cout, Fin)) return IDV_EINVAL;
+    if (!idv_cconv_wino_supported(transposed, C0, C1, Cout, Fin)) return IDV_EINVAL;
     if ((Jp & 3) || (reinterpret_cast<uintptr_t>(x0) & 15) || (C1 > 0 && (reinterpret_cast<uintptr_t>(x1) & 15))) return IDV_EINVAL;
     WinoArgs a{};
     a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1;
-    a.Fin = Fin; a.Fout = 2 * Fin - 1;
+    a.Fin = Fin; a.Fout = transposed ? 2 * Fin - 1 : (Fin - 1) / 2 + 1;
     a.J = B * Tp; a.Jp = Jp; a.Tp = Tp;
     a.wfrag = wfrag; a.UN = (C0 + C1 + WCIK - 1) / WCIK * WCIK * 3; a.epi = epi; a.has_fold = has_fold; a.slope = prelu_slope; a.out = out;
     a.Cout = Cout; a.cotiles = (Cout + 31) / 32;
@@ -484,17 +536,18 @@ extern "C" int idv_ctconv2d_wino_fwd(const float* x0, int C0, const float* x1, i
     a.stats = stats;
     if (stats && stats_work) { a.stats = stats_work; a.stats_rep = stats_rep; }       // replicated sums, folded afterwards (common.hpp)
     int rc;
-    // experiments: IDV_WINO_CFG = WM WN CIK as decimal digits (e.g. 418: four co tiles x one column group, 8 channels per chunk)
+    // experiments: IDV_WINO_CFG / IDV_WINO_CCFG = WM WN CIK as decimal digits for the transposed conv / the conv
     static const int xcfg = [] { const char* e = getenv("IDV_WINO_CFG"); return e ? atoi(e) : 0; }();
-    int cfg = xcfg ? xcfg : idv_ctconv_wino_config(C0 + C1, Cout);
+    static const int xccfg = [] { const char* e = getenv("IDV_WINO_CCFG"); return e ? atoi(e) : 0; }();
+    int cfg = transposed ? xcfg : xccfg;
+    if (!cfg) cfg = idv_cconv_wino_config(transposed, C0 + C1, Cout);
     if (C1 > 0 && C0 % (cfg % 10)) cfg = cfg / 10 * 10 + 4;          // a K chunk must not straddle the two sources (C0 % 4 == 0 holds)
     switch (cfg) {
-        case 414: rc = launch_wino<4, 1, 4>(a, st); break;
-        case 418: rc = launch_wino<4, 1, 8>(a, st); break;
-        case 224: rc = launch_wino<2, 2, 4>(a, st); break;
-        case 228: rc = launch_wino<2, 2, 8>(a, st); break;
-        case 144: rc = launch_wino<1, 4, 4>(a, st); break;
-        case 142: rc = launch_wino<1, 4, 2>(a, st); break;
+        case 414: rc = launch_wino<4, 1, 4>(a, transposed, st); break;
+        case 418: rc = launch_wino<4, 1, 8>(a, transposed, st); break;
+        case 224: rc = launch_wino<2, 2, 4>(a, transposed, st); break;
+        case 228: rc = launch_wino<2, 2, 8>(a, transposed, st); break;
+        case 144: rc = launch_wino<1, 4, 4>(a, transposed, st); break;
         default: return IDV_EINVAL;
     }
     if (rc || !(stats && stats_work)) return rc;

@@ -264,23 +264,28 @@ def pack_cconv_gauss(w_re, w_im, b_re, b_im, fold, cin_used: Optional[int] = Non
     return wfrag, epi, (1 if fold is not None else 0), _pack_wino(w_re, w_im, cout, cin_total, cin_used, transposed, 0)
 
 
-# fp32 transposed convs with Winograd-transformed frequency taps on top of the three-product form (csrc/cgemm_wino.hip):
-# 7 instead of 10 real products per input channel and pair of input rows.  IDV_WINO=0 (or ops.WINO = False) keeps cgemm_gauss.
+# fp32 convs / transposed convs with Winograd-transformed frequency taps on top of the three-product form (csrc/cgemm_wino.hip):
+# 7 instead of 10 real products per input channel and pair of rows.  IDV_WINO=0 (or ops.WINO = False) keeps cgemm_gauss.
 WINO = os.environ.get("IDV_WINO", "1") != "0"
-WINO_CFG = 4000000               # LAUNCH_LOG ids: WINO_CFG + idv_ctconv_wino_config
+WINO_CFG = 4000000               # LAUNCH_LOG ids: WINO_CFG + (1000 if transposed) + idv_cconv_wino_config
 
 
 def _pack_wino(w_re, w_im, cout: int, cin_total: int, cin_used: int, transposed: bool, conj: int):
-    """Winograd-transformed Gauss planes for a transposed operator (a ComplexConvTranspose2d, or the adjoint of a ComplexConv2d:
-    transposed here is the OPERATOR's mode); None where the kernel does not apply."""
-    if not (WINO and transposed):
+    """Winograd-transformed Gauss planes of an operator (transposed = the OPERATOR's mode: a ComplexConvTranspose2d or the adjoint
+    of a ComplexConv2d; a ComplexConv2d or the adjoint of a transposed one), flags exactly as idv_pack_cconv_gauss gets them."""
+    if not WINO:
         return None
-    n = int(_ll_fn("idv_ctconv_wino_wfrag_floats")(i(cout), i(cin_used)))
+    n = int(_ll_fn("idv_cconv_wino_wfrag_floats")(i(1 if transposed else 0), i(cout), i(cin_used)))
     wf = torch.empty(n, dtype=torch.float32, device=w_re.device)
-    # same flags as idv_pack_cconv_gauss gets for this operator: mode 1 = the tensor is read as [Cin][Cout][5][2] (a transposed
-    # conv's own weight, or a conv's [Cout'][Cin'] weight seen from its adjoint), conj negates W_i (adjoint)
-    call("idv_pack_ctconv_wino", p(w_re), p(w_im), i(cout), i(cin_total), i(cin_used), i(1), i(conj), p(wf), stream_ptr())
+    call("idv_pack_cconv_wino", p(w_re), p(w_im), i(cout), i(cin_total), i(cin_used), i(1 if transposed else 0), i(conj), p(wf),
+         stream_ptr())
     return wf
+
+
+def _wino_ok(gauss, transposed: bool, x: Planar, c1: int, cout: int, skip_jp: Optional[int]) -> bool:
+    return (gauss is not None and WINO and len(gauss) > 3 and gauss[3] is not None and x.Jp % 4 == 0
+            and (skip_jp is None or skip_jp == x.Jp)
+            and bool(L.lib().idv_cconv_wino_supported(i(1 if transposed else 0), i(x.C), i(c1), i(cout), i(x.F))))
 
 
 def pack_cconv_gauss_skip_part(w_re, w_im, c0: int):
@@ -503,17 +508,15 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
             ev1.record()
             LAUNCH_LOG.append((cfg, macs, ev0, ev1))
         return out
-    if (gauss is not None and transposed and WINO and len(gauss) > 3 and gauss[3] is not None and skip_div == 1
-            and (skip is None or skip.Jp == x.Jp) and x.Jp % 4 == 0
-            and L.lib().idv_ctconv_wino_supported(i(x.C), i(c1), i(cout), i(x.F))):
-        # fp32 transposed conv: Winograd-transformed frequency taps on top of the three products (csrc/cgemm_wino.hip)
+    if skip_div == 1 and _wino_ok(gauss, transposed, x, c1, cout, skip.Jp if skip is not None else None):
+        # fp32: Winograd-transformed frequency taps on top of the three products (csrc/cgemm_wino.hip)
         if LAUNCH_LOG is not None:
-            cfg = WINO_CFG + L.lib().idv_ctconv_wino_config(i(x.C + c1), i(cout))
+            cfg = WINO_CFG + (1000 if transposed else 0) + L.lib().idv_cconv_wino_config(i(1 if transposed else 0), i(x.C + c1), i(cout))
         swork = _stats_work(stats, cout)
-        call("idv_ctconv2d_wino_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1), p(gauss[3]), p(gauss[1]),
-             i(gauss[2]), p(slope), out.ptr(), p(stats), p(swork), i(STATS_REP), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp),
-             i(t_out), addend.ptr() if addend is not None else p(None), i(addend_div), i(addend.Jp if addend is not None else 0),
-             stream_ptr())
+        call("idv_cconv2d_wino_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1), p(gauss[3]), p(gauss[1]),
+             i(gauss[2]), p(slope), out.ptr(), p(stats), p(swork), i(STATS_REP), i(1 if transposed else 0), i(tshift), i(cout), i(x.F),
+             i(x.B), i(x.Tp), i(x.Jp), i(t_out), addend.ptr() if addend is not None else p(None), i(addend_div),
+             i(addend.Jp if addend is not None else 0), stream_ptr())
     elif gauss is not None:
         # fp32: three real products per complex product (csrc/cgemm_gauss.hip); gauss = (wfrag3, epi, has_fold[, wino fragments])
         if LAUNCH_LOG is not None:
@@ -958,13 +961,13 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
         if wfrag_bf16 is not None:
             cfg = -(1000000 + L.lib().idv_cconv_bf16_config(i(1 if adj_transposed else 0), i(cout_adj), i(dy.F)))
         ev0.record()
-    if (gauss is not None and wfrag_bf16 is None and adj_transposed and WINO and len(gauss) > 3 and gauss[3] is not None
-            and dy.Jp % 4 == 0 and L.lib().idv_ctconv_wino_supported(i(dy.C), i(0), i(cout_adj), i(dy.F))):
-        # data gradient of a conv = a transposed conv: Winograd form (csrc/cgemm_wino.hip)
+    if wfrag_bf16 is None and _wino_ok(gauss, adj_transposed, dy, 0, cout_adj, None):
+        # the data gradient on the Winograd kernels (csrc/cgemm_wino.hip): adjoint of a conv = a transposed conv and vice versa
         if LAUNCH_LOG is not None:
-            cfg = WINO_CFG + L.lib().idv_ctconv_wino_config(i(dy.C), i(cout_adj))
-        call("idv_ctconv2d_wino_fwd", dy.ptr(), i(dy.C), p(None), i(0), p(gauss[3]), p(gauss[1]), i(0), p(None), out.ptr(), p(None), p(None),
-             i(0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), p(None), i(1), i(0), stream_ptr())
+            cfg = WINO_CFG + (1000 if adj_transposed else 0) + L.lib().idv_cconv_wino_config(i(1 if adj_transposed else 0), i(dy.C), i(cout_adj))
+        call("idv_cconv2d_wino_fwd", dy.ptr(), i(dy.C), p(None), i(0), p(gauss[3]), p(gauss[1]), i(0), p(None), out.ptr(), p(None), p(None),
+             i(0), i(1 if adj_transposed else 0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), p(None), i(1),
+             i(0), stream_ptr())
     elif gauss is not None and wfrag_bf16 is None:
         if LAUNCH_LOG is not None:
             cfg = L.lib().idv_cconv_gauss_config(i(1 if adj_transposed else 0), i(dy.C), i(cout_adj), i(dy.F))

@@ -577,22 +577,22 @@ int idv_bucket_adam(const long long* ptable, const long long* gtable, const floa
                     int n, long long total, float lr, double beta1, double beta2, float eps, float weight_decay,
                     float bias_correction1, float bias_correction2_sqrt, float grad_scale, void* stream);
 
-/* ---- transposed complex conv with Winograd-transformed frequency taps (cgemm_wino.hip) --------------------------------------
- * The decoder block's contraction (model/complex_progress.py:222-279) with 7 instead of 10 real products per input channel and
- * pair of input rows (F(2,3) on the even, F(2,2) on the odd frequency taps) on top of the three-product complex form of
- * idv_cconv2d_gauss_fwd; same result up to the rounding of the transforms.  idv_pack_ctconv_wino: weights as idv_pack_cconv_gauss
- * (transposed / conj conventions), wfrag of idv_ctconv_wino_wfrag_floats(Cout, cin_used) floats; the epilogue table (epi,
- * has_fold) is idv_pack_cconv_gauss's.  idv_ctconv2d_wino_fwd: arguments as idv_cconv2d_gauss_fwd with transposed = 1,
- * x1_div = 1 and both sources at pitch Jp (Jp % 4 == 0, 16-byte aligned).  IDV_WINO=0 turns it off. */
-int idv_ctconv_wino_supported(int C0, int C1, int Cout, int Fin);
-long long idv_ctconv_wino_wfrag_floats(int Cout, int cin_used);
-int idv_ctconv_wino_config(int Cin, int Cout);
-int idv_pack_ctconv_wino(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used, int transposed, int conj,
-                         float* wfrag, void* stream);
-int idv_ctconv2d_wino_fwd(const float* x0, int C0, const float* x1, int C1, const float* wfrag, const float* epi, int has_fold,
-                          const float* prelu_slope, float* out, double* stats, double* stats_work, int stats_rep, int tshift,
-                          int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, const float* addend, int addend_div,
-                          int addend_Jp, void* stream);
+/* ---- complex conv / transposed conv with Winograd-transformed frequency taps (cgemm_wino.hip) -------------------------------
+ * The encoder / decoder blocks' contractions (model/complex_progress.py:8-36, :222-279) with 7 instead of 10 real products per
+ * input channel and pair of rows (F(2,3) on the even, F(2,2) on the odd frequency taps) on top of the three-product complex form
+ * of idv_cconv2d_gauss_fwd; same result up to the rounding of the transforms.  idv_pack_cconv_wino: weights as
+ * idv_pack_cconv_gauss (transposed / conj conventions), wfrag of idv_cconv_wino_wfrag_floats floats; the epilogue table (epi,
+ * has_fold) is idv_pack_cconv_gauss's.  idv_cconv2d_wino_fwd: arguments as idv_cconv2d_gauss_fwd with x1_div = 1 and both
+ * sources at pitch Jp (Jp % 4 == 0, 16-byte aligned).  IDV_WINO=0 turns it off (IDV_WINO_CONV=0: the conv form only). */
+int idv_cconv_wino_supported(int transposed, int C0, int C1, int Cout, int Fin);
+long long idv_cconv_wino_wfrag_floats(int transposed, int Cout, int cin_used);
+int idv_cconv_wino_config(int transposed, int Cin, int Cout);
+int idv_pack_cconv_wino(const float* w_re, const float* w_im, int Cout, int Cin_total, int Cin_used, int transposed, int conj,
+                        float* wfrag, void* stream);
+int idv_cconv2d_wino_fwd(const float* x0, int C0, const float* x1, int C1, const float* wfrag, const float* epi, int has_fold,
+                         const float* prelu_slope, float* out, double* stats, double* stats_work, int stats_rep, int transposed,
+                         int tshift, int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, const float* addend,
+                         int addend_div, int addend_Jp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -109,30 +109,42 @@ def test_cconv_gauss(ops, causal, transposed, cin, cout, F, T, B, skip_c, skip_d
                gauss=True)
 
 
-@pytest.mark.parametrize("causal,cin,cout,F,T,B,skip_c,fold,slope", [
-    (True, 8, 40, 9, 37, 3, 0, True, 0.2),          # two co tiles x two column groups (ragged second co tile), odd row count
-    (True, 16, 128, 5, 30, 2, 0, False, None),      # four co tiles x one column group
-    (True, 8, 12, 17, 21, 5, 0, True, 0.3),         # one co tile x four column groups (128-column patch)
-    (True, 8, 8, 6, 30, 2, 8, False, None),         # even row count, skip concat (second source)
-    (True, 6, 4, 2, 9, 2, 0, False, 0.1),           # two input rows (one tile), channel count below the pack granularity
-    (True, 7, 36, 3, 45, 1, 0, True, None),         # odd channel count: ragged last K chunk
-    (False, 6, 4, 9, 9, 2, 0, False, None),         # non-causal taps (T + 1 output frames)
-    (True, 32, 32, 33, 645, 2, 32, False, 0.25),    # utterance-length columns, Tp = 646, column tail
-    (True, 256, 64, 17, 70, 2, 0, True, 0.25),      # a real layer width (dec3's channels)
+@pytest.mark.parametrize("transposed,causal,cin,cout,F,T,B,skip_c,fold,slope", [
+    (True, True, 8, 40, 9, 37, 3, 0, True, 0.2),          # two co tiles x two column groups (ragged second co tile), odd row count
+    (True, True, 16, 128, 5, 30, 2, 0, False, None),      # four co tiles x one column group
+    (True, True, 8, 8, 6, 30, 2, 8, False, None),         # one co tile: NOT served (cgemm_gauss runs), skip concat
+    (True, True, 8, 40, 6, 30, 2, 8, False, None),        # even row count, skip concat (second source)
+    (True, True, 6, 36, 2, 9, 2, 0, False, 0.1),          # two input rows (one tile), channel count below the pack granularity
+    (True, True, 7, 36, 3, 45, 1, 0, True, None),         # odd channel count: ragged last K chunk
+    (True, False, 6, 40, 9, 9, 2, 0, False, None),        # non-causal taps (T + 1 output frames)
+    (True, True, 32, 64, 33, 645, 2, 32, False, 0.25),    # utterance-length columns, Tp = 646, column tail
+    (True, True, 256, 64, 17, 70, 2, 0, True, 0.25),      # a real layer width (dec3's channels)
+    (False, True, 32, 64, 129, 70, 2, 0, False, None),    # conv: two co tiles x two column groups, odd output row count (65)
+    (False, True, 8, 40, 65, 33, 2, 0, True, 0.2),        # conv: ragged second co tile, fold + PReLU
+    (False, True, 16, 128, 17, 40, 3, 0, False, None),    # conv: four co tiles x one column group
+    (False, True, 3, 36, 9, 21, 2, 0, False, 0.1),        # conv: odd channel count, 5 output rows (three tiles, the last half empty)
+    (False, False, 4, 40, 17, 9, 2, 0, False, None),      # conv: non-causal taps (x[t], x[t+1])
+    (False, True, 2, 48, 5, 700, 1, 0, False, None),      # conv: many column tiles, 3 output rows
+    (False, True, 128, 128, 33, 70, 2, 0, True, 0.25),    # conv: a real layer width (enc3), 17 output rows (last tile half empty)
+    (False, True, 130, 160, 9, 21, 2, 0, False, 0.1),     # conv: ragged last K chunk, five co tiles (second workgroup: one valid tile)
+    (False, False, 128, 128, 17, 9, 2, 0, False, None),   # conv: non-causal taps at a served width
+    (False, True, 136, 128, 4, 30, 3, 0, True, None),     # conv: even input row count (Fout = 2: one tile)
+    (False, True, 6, 36, 4, 30, 2, 0, False, None),       # conv below the served widths: cgemm_gauss runs
 ])
-def test_ctconv_wino(ops, causal, cin, cout, F, T, B, skip_c, fold, slope):
-    """The transposed conv with Winograd-transformed frequency taps (csrc/cgemm_wino.hip: F(2,3) on the even, F(2,2) on the odd
-    taps, on top of the three complex products) against the oracle's four real transposed convolutions AND against
-    cgemm_gauss_kernel, in its three workgroup shapes."""
+def test_cconv_wino(ops, transposed, causal, cin, cout, F, T, B, skip_c, fold, slope):
+    """The conv / transposed conv with Winograd-transformed frequency taps (csrc/cgemm_wino.hip: F(2,3) on the even, F(2,2) on the
+    odd taps, on top of the three complex products) against the oracle's four real convolutions AND against cgemm_gauss_kernel, in
+    its workgroup shapes."""
     keep, keep_log = ops.WINO, ops.LAUNCH_LOG
+    served = bool(ops.L.lib().idv_cconv_wino_supported(int(transposed), cin, skip_c, cout, F))
     try:
         ops.WINO = True
         ops.LAUNCH_LOG = []
-        got = _conv_case(ops, causal, True, cin, cout, F, T, B, seed=61, fold=fold, slope=slope, skip_c=skip_c, gauss=True)
-        assert [c for c, *_ in ops.LAUNCH_LOG if c >= ops.WINO_CFG], "the Winograd kernel was not launched"
+        got = _conv_case(ops, causal, transposed, cin, cout, F, T, B, seed=61, fold=fold, slope=slope, skip_c=skip_c, gauss=True)
+        assert bool([c for c, *_ in ops.LAUNCH_LOG if c >= ops.WINO_CFG]) == served, "Winograd kernel launched / not launched"
         ops.WINO = False
         ops.LAUNCH_LOG = []
-        ref = _conv_case(ops, causal, True, cin, cout, F, T, B, seed=61, fold=fold, slope=slope, skip_c=skip_c, gauss=True)
+        ref = _conv_case(ops, causal, transposed, cin, cout, F, T, B, seed=61, fold=fold, slope=slope, skip_c=skip_c, gauss=True)
         assert not [c for c, *_ in ops.LAUNCH_LOG if c >= ops.WINO_CFG]
     finally:
         ops.WINO, ops.LAUNCH_LOG = keep, keep_log
