@@ -403,6 +403,16 @@ def kernel_name(cfg_id):
     return f"void (anonymous namespace)::cgemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {d[4]}, false, {d[5]}, false, 2>(CgemmArgs)"
 
 
+def kernel_parts(cfg_id):
+    """The kernel name(s), as rocprofv3 prints them, behind one timed launch of configuration cfg_id: one name, except for a
+    transposed-conv layer on the Winograd form (even-row phase kernel + odd-row phase kernel)."""
+    if 4001000 <= cfg_id < 5000000:
+        d = str((cfg_id - 4000000) % 1000)
+        return [f"void (anonymous namespace)::cconv_wino_kernel<0, {d[0]}, {d[1]}, {d[2]}, 3, false, 1, 0>((anonymous namespace)::WinoArgs)",
+                f"void (anonymous namespace)::cconv_wino_kernel<1, {d[0]}, {d[1]}, {d[2]}, 3, false, 2, 8>((anonymous namespace)::WinoArgs)"]
+    return [kernel_name(cfg_id)]
+
+
 def group_launches(entries):
     out = {}
     for cfg_id, macs, e0, e1 in entries:
@@ -426,12 +436,12 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
     peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     ach = 2 * macs / secs / 1e12
     traffic, tsrc = None, None
-    tname = "r03_traffic_f32.json" if precision == "fp32" else "r03_traffic_bf16x3.json"
+    tname = "r04_traffic_f32.json" if precision == "fp32" else "r04_traffic_bf16x3.json"
     tpath = os.path.join(ROOT, "profiles", tname)
     if os.path.exists(tpath) and batch == DEFAULT_BATCH and workload == "dccrn_cl":
-        tk = json.load(open(tpath))["kernels"].get(kernel_name(dom))
-        if tk:
-            traffic, tsrc = tk["hbm_bytes_per_launch"], "profiles/" + tname
+        tks = [json.load(open(tpath))["kernels"].get(nm) for nm in kernel_parts(dom)]
+        if all(tks):                           # a transposed-conv layer on the Winograd form is TWO kernels: their traffic adds up
+            traffic, tsrc = sum(tk["hbm_bytes_per_launch"] for tk in tks), "profiles/" + tname
     r = {
         "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
         "traffic": traffic,
@@ -440,7 +450,7 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
                         "null when the run differs from that command",
         "peak_note": ("dense bf16 MFMA peak; achieved counts ALGORITHMIC fp32 flops (4 real convs), the kernel executes 3 bf16 "
                       "MFMA products per algorithmic product" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
-        "kernel": kernel_name(dom), "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
+        "kernel": kernel_name(dom), "kernel_parts": kernel_parts(dom), "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
         "algorithmic_gflop_per_launch": round(2 * macs / n / 1e9, 3),
         "all_conv_launches": {"achieved": round(2 * tot_macs / tot_secs / 1e12, 3),
                               "frac": round(2 * tot_macs / tot_secs / 1e12 / peak, 4),
@@ -456,7 +466,8 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
         r["peak_note"] = ("dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32); achieved counts ALGORITHMIC flops (the reference's 4 real "
                           "convolutions x 10 taps per complex transposed convolution, SURVEY 8(d)); the kernels execute 3 real products "
                           "(Gauss) x 7 of 10 frequency-tap products (Winograd F(2,3) + F(2,2)): `executed` = 0.525 x achieved, "
-                          "excluding the padding row of an odd row count")
+                          "excluding the padding row of an odd row count.  One `launch` here = one decoder layer = the even-row and the odd-row "
+                          "phase kernel back to back (kernel_parts): avg_launch_ms = the sum of their average durations in the rocprofv3 summary")
     if 3000000 <= dom < 4000000 or dom == -95:
         # three real products per complex product (Gauss, cgemm_gauss.hip): `achieved` counts the reference's 4 real convolutions
         r["executed"] = round(0.75 * ach, 3)

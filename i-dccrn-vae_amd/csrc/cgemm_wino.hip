@@ -429,7 +429,10 @@ int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
     static_assert(smem * OCC <= 160 * 1024, "the patch buffers of OCC workgroups must fit the 160 KB of LDS");
     WinoArgs b = a;
     b.jtiles = (a.J + JT - 1) / JT;
-    b.ftiles = ((PH == 2 ? a.Fout : a.Fin) + 1) / 2;
+    // row tiles: pairs of input rows (transposed) / output rows (conv).  With an odd number of input rows the last pair's second
+    // row does not exist and BOTH odd output rows of that tile (2 Fin - 1, 2 Fin + 1) lie outside the output: the odd-row phase
+    // skips the tile (a third of its work on the 5-row dec0, a fifth on dec1)
+    b.ftiles = PH == 2 ? (a.Fout + 1) / 2 : (PH == 1 ? a.Fin / 2 : (a.Fin + 1) / 2);
     b.mblocks = (a.cotiles + WM - 1) / WM;
     const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
