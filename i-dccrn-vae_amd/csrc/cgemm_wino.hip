@@ -57,6 +57,7 @@ struct WinoArgs {
     const float* add;     // optional addend (see cgemm_gauss.hip)
     int add_div, add_Jp;
     int jtiles, ftiles, mblocks;
+    int ft0;              // first row tile of this launch (the half-tile launch handles the last tile alone)
 };
 
 constexpr int WCIK = 8;          // pack granularity in complex input channels (= cgemm_gauss's: shared `supported` rule); the kernel's K
@@ -88,7 +89,9 @@ template <int PH> constexpr int wino_slots() { return PH == 2 ? 8 : 4; }        
 constexpr int wino_acc2(int q) { return q < 4 ? q : (q == 4 ? 0 : (q == 5 ? 1 : 3)); }
 
 // OCC: workgroups per CU the kernel is built for (2: at most 256 registers); RD: depth of the weight ring in units (0: a whole chunk)
-template <int PH, int WM, int WN, int CIK, int NBUF, bool STATS, int OCC = 1, int RDP = 0>
+// HALF: the tile's SECOND output row does not exist (last tile of an odd row count): the products that only feed it are skipped
+// (PH 0: M4; PH 2: the two into A3)
+template <int PH, int WM, int WN, int CIK, int NBUF, bool STATS, int OCC = 1, int RDP = 0, bool HALF = false>
 __global__ __launch_bounds__(WM* WN * 64, OCC) void cconv_wino_kernel(const WinoArgs a) {
     constexpr int NT = WM * WN * 64;
     constexpr int TR = wino_tr<PH>();             // transformed patch rows per (channel, plane) = products per (channel, plane)
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void cconv_wino_kernel(const Wino
     const int sg = bid / per, rem = bid - sg * per;
     const int v = rem >> 3;
     const int jt = sg * 8 + (rem & 7);
-    const int ft = v / MB;
-    const int mblk = v - ft * MB;
+    const int ft = a.ft0 + v / MB;
+    const int mblk = v - (v / MB) * MB;
     if (jt >= a.jtiles) return;
     const int j0 = jt * JT;
     const int ct = mblk * WM + wm;
@@ -268,6 +271,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void cconv_wino_kernel(const Wino
                 constexpr int dummy = 0;
                 (void)dummy;
                 const int ai = PH == 2 ? wino_acc2(q) : q;
+                if (HALF && ai == 3) continue;            // feeds the missing second output row only
                 acc[ai][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][q], b_cur[q], acc[ai][p3], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -431,17 +435,34 @@ int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
     b.jtiles = (a.J + JT - 1) / JT;
     // row tiles: pairs of input rows (transposed) / output rows (conv).  With an odd number of input rows the last pair's second
     // row does not exist and BOTH odd output rows of that tile (2 Fin - 1, 2 Fin + 1) lie outside the output: the odd-row phase
-    // skips the tile (a third of its work on the 5-row dec0, a fifth on dec1)
-    b.ftiles = PH == 2 ? (a.Fout + 1) / 2 : (PH == 1 ? a.Fin / 2 : (a.Fin + 1) / 2);
+    // skips the tile (a third of its work on the 5-row dec0, a fifth on dec1).  In the even-row phase and in the conv the last tile
+    // of an odd row count has ONE output row: it runs as its own launch of the HALF variant, which skips the products that only
+    // feed the missing row (1 of 4 / 2 of 7)
+    const int rows = PH == 2 ? a.Fout : a.Fin;
+    const int full = rows / 2, half = (PH != 1 && (rows & 1)) ? 1 : 0;
     b.mblocks = (a.cotiles + WM - 1) / WM;
-    const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
-    if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = cconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS, OCC, RD>;
     // OCC 1: more than half a CU's LDS, i.e. one workgroup per CU whatever the register count says
     const size_t smem_req = OCC == 1 ? (smem > 84 * 1024 ? smem : 84 * 1024) : smem;
+    auto k = cconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS, OCC, RD, false>;
+    auto kh = cconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS, OCC, RD, true>;
     if (smem_req > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req) != hipSuccess) return IDV_ELAUNCH;
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(WM * WN * 64), smem_req, st, b);
+        (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req) != hipSuccess ||
+         hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req) != hipSuccess))
+        return IDV_ELAUNCH;
+    static const bool use_half = [] { const char* e = getenv("IDV_WINO_HALF"); return !e || e[0] != '0'; }();
+    if (full + (use_half ? 0 : half) > 0) {
+        b.ft0 = 0;
+        b.ftiles = full + (use_half ? 0 : half);
+        const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
+        if (nblk > 0x7fffffffLL) return IDV_EINVAL;
+        hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(WM * WN * 64), smem_req, st, b);
+    }
+    if (half && use_half) {
+        b.ft0 = full;
+        b.ftiles = 1;
+        const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.mblocks;
+        hipLaunchKernelGGL(kh, dim3((unsigned)nblk), dim3(WM * WN * 64), smem_req, st, b);
+    }
     return idv_launch_status();
 }
 
@@ -453,7 +474,13 @@ template <int WM, int WN, int CIK, bool STATS>
 int launch_wino_s(const WinoArgs& a, int transposed, hipStream_t st) {
     if (!transposed) return launch_wino_ph<2, WM, WN, CIK, STATS, 1, (CIK * 3) / 2>(a, st);
     static const int ph1 = [] { const char* e = getenv("IDV_WINO_PH1"); return e ? atoi(e) : 1; }();
-    if (int rc = launch_wino_ph<0, WM, WN, CIK, STATS>(a, st)) return rc;
+    // the even-row phase of the four-co-tile form runs at two workgroups per CU too -- four channels per chunk and a weight ring of
+    // four units make it fit: 249 registers, accumulators in VGPRs -- dec0 11.09 -> 10.49 ms, dec1 10.13 -> 9.62, dec2 9.67 -> 9.03
+    // (B = 64); the 2 x 2 form needs two staging items per thread and spills there.  IDV_WINO_PH0=1: one workgroup per CU
+    static const int ph0 = [] { const char* e = getenv("IDV_WINO_PH0"); return e ? atoi(e) : 2; }();
+    if (ph0 == 2 && WM == 4 && WN == 1) {
+        if (int rc = launch_wino_ph<0, 4, 1, 4, STATS, 2, 4>(a, st)) return rc;
+    } else if (int rc = launch_wino_ph<0, WM, WN, CIK, STATS>(a, st)) return rc;
     if (ph1 == 0) return launch_wino_ph<1, WM, WN, CIK, STATS>(a, st);
     return launch_wino_ph<1, WM, WN, CIK, STATS, 2, (CIK * 3) % 8 == 0 ? 8 : 6>(a, st);
 }
