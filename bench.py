@@ -408,7 +408,8 @@ def kernel_parts(cfg_id):
     transposed-conv layer on the Winograd form (even-row phase kernel + odd-row phase kernel)."""
     if 4001000 <= cfg_id < 5000000:
         d = str((cfg_id - 4000000) % 1000)
-        even = "4, 3, false, 2, 4, false" if d[:2] == "41" else f"{d[2]}, 3, false, 1, 0, false"      # four co tiles: two workgroups per CU
+        # even-row phase at two workgroups per CU: four channels per chunk (4 x 1 waves) / two (2 x 2)
+        even = "4, 3, false, 2, 4, false" if d[:2] == "41" else ("2, 3, false, 2, 3, false" if d[:2] == "22" else f"{d[2]}, 3, false, 1, 0, false")
         return [f"void (anonymous namespace)::cconv_wino_kernel<0, {d[0]}, {d[1]}, {even}>((anonymous namespace)::WinoArgs)",
                 f"void (anonymous namespace)::cconv_wino_kernel<1, {d[0]}, {d[1]}, {d[2]}, 3, false, 2, 8, false>((anonymous namespace)::WinoArgs)",
                 # the even-row phase's last tile of an odd row count (every DCCRN layer has one): the half-tile variant

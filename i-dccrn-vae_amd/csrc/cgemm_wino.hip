@@ -474,12 +474,15 @@ template <int WM, int WN, int CIK, bool STATS>
 int launch_wino_s(const WinoArgs& a, int transposed, hipStream_t st) {
     if (!transposed) return launch_wino_ph<2, WM, WN, CIK, STATS, 1, (CIK * 3) / 2>(a, st);
     static const int ph1 = [] { const char* e = getenv("IDV_WINO_PH1"); return e ? atoi(e) : 1; }();
-    // the even-row phase of the four-co-tile form runs at two workgroups per CU too -- four channels per chunk and a weight ring of
-    // four units make it fit: 249 registers, accumulators in VGPRs -- dec0 11.09 -> 10.49 ms, dec1 10.13 -> 9.62, dec2 9.67 -> 9.03
-    // (B = 64); the 2 x 2 form needs two staging items per thread and spills there.  IDV_WINO_PH0=1: one workgroup per CU
+    // the even-row phase runs at two workgroups per CU too where it fits 256 registers (accumulators in VGPRs): the four-co-tile
+    // form with four channels per chunk and a weight ring of four units (249 registers): dec0 11.09 -> 10.49 ms, dec1 10.13 -> 9.62,
+    // dec2 9.67 -> 9.03 (B = 64); the 2 x 2 form with two channels per chunk (one staging item per thread; with four it needs two
+    // and spills) and a ring of three: dec3 10.37 -> 9.99.  IDV_WINO_PH0=1: one workgroup per CU
     static const int ph0 = [] { const char* e = getenv("IDV_WINO_PH0"); return e ? atoi(e) : 2; }();
     if (ph0 == 2 && WM == 4 && WN == 1) {
         if (int rc = launch_wino_ph<0, 4, 1, 4, STATS, 2, 4>(a, st)) return rc;
+    } else if (ph0 == 2 && WM == 2 && WN == 2) {
+        if (int rc = launch_wino_ph<0, 2, 2, 2, STATS, 2, 3>(a, st)) return rc;
     } else if (int rc = launch_wino_ph<0, WM, WN, CIK, STATS>(a, st)) return rc;
     if (ph1 == 0) return launch_wino_ph<1, WM, WN, CIK, STATS>(a, st);
     return launch_wino_ph<1, WM, WN, CIK, STATS, 2, (CIK * 3) % 8 == 0 ? 8 : 6>(a, st);
