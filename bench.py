@@ -377,9 +377,9 @@ def kernel_name(cfg_id):
     if 4000000 <= cfg_id < 5000000:       # ops.WINO_CFG + 1000 * transposed + idv_cconv_wino_config digits WM WN CIK
         tr, d = (cfg_id - 4000000) // 1000, str((cfg_id - 4000000) % 1000)
         if tr:                                # the two phase kernels of a transposed-conv layer (+ their half-tile variants)
-            a, b = kernel_parts(cfg_id)[:2]
+            a, b = kernel_parts(cfg_id)
             return a.replace("((anonymous namespace)::WinoArgs)", "") + " + " + b.replace("void (anonymous namespace)::cconv_wino_kernel", "")
-        return (f"void (anonymous namespace)::cconv_wino_kernel<2, {d[0]}, {d[1]}, {d[2]}, 3, false, 1, {3 * int(d[2]) // 2}, false>"
+        return (f"void (anonymous namespace)::cconv_wino_kernel<2, {d[0]}, {d[1]}, {d[2]}, 3, false, 1, {3 * int(d[2]) // 2}>"
                 "((anonymous namespace)::WinoArgs)")
     if 3000000 <= cfg_id < 4000000:       # idv_cconv_gauss_config digits 3 MODE WM WN FO_T JC_W OCC
         d = str(cfg_id)
@@ -409,11 +409,9 @@ def kernel_parts(cfg_id):
     if 4001000 <= cfg_id < 5000000:
         d = str((cfg_id - 4000000) % 1000)
         # even-row phase at two workgroups per CU: four channels per chunk (4 x 1 waves) / two (2 x 2)
-        even = "4, 3, false, 2, 4, false" if d[:2] == "41" else ("2, 3, false, 2, 3, false" if d[:2] == "22" else f"{d[2]}, 3, false, 1, 0, false")
+        even = "4, 3, false, 2, 4" if d[:2] == "41" else ("2, 3, false, 2, 3" if d[:2] == "22" else f"{d[2]}, 3, false, 1, 0")
         return [f"void (anonymous namespace)::cconv_wino_kernel<0, {d[0]}, {d[1]}, {even}>((anonymous namespace)::WinoArgs)",
-                f"void (anonymous namespace)::cconv_wino_kernel<1, {d[0]}, {d[1]}, {d[2]}, 3, false, 2, 8, false>((anonymous namespace)::WinoArgs)",
-                # the even-row phase's last tile of an odd row count (every DCCRN layer has one): the half-tile variant
-                f"void (anonymous namespace)::cconv_wino_kernel<0, {d[0]}, {d[1]}, {even[:-5]}true>((anonymous namespace)::WinoArgs)"]
+                f"void (anonymous namespace)::cconv_wino_kernel<1, {d[0]}, {d[1]}, {d[2]}, 3, false, 2, 8>((anonymous namespace)::WinoArgs)"]
     return [kernel_name(cfg_id)]
 
 
@@ -444,8 +442,8 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
     tpath = os.path.join(ROOT, "profiles", tname)
     if os.path.exists(tpath) and batch == DEFAULT_BATCH and workload == "dccrn_cl":
         tks = [json.load(open(tpath))["kernels"].get(nm) for nm in kernel_parts(dom)]
-        if all(tks[:2]):                       # a transposed-conv layer on the Winograd form is two kernels (+ the half-tile
-            traffic, tsrc = sum(tk["hbm_bytes_per_launch"] for tk in tks if tk), "profiles/" + tname     # variant): traffic adds up
+        if all(tks):                           # a transposed-conv layer on the Winograd form is TWO kernels: their traffic adds up
+            traffic, tsrc = sum(tk["hbm_bytes_per_launch"] for tk in tks), "profiles/" + tname
     r = {
         "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
         "traffic": traffic,

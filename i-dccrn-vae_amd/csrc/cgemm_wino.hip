@@ -57,7 +57,6 @@ struct WinoArgs {
     const float* add;     // optional addend (see cgemm_gauss.hip)
     int add_div, add_Jp;
     int jtiles, ftiles, mblocks;
-    int ft0;              // first row tile of this launch (the half-tile launch handles the last tile alone)
 };
 
 constexpr int WCIK = 8;          // pack granularity in complex input channels (= cgemm_gauss's: shared `supported` rule); the kernel's K
@@ -89,9 +88,7 @@ template <int PH> constexpr int wino_slots() { return PH == 2 ? 8 : 4; }        
 constexpr int wino_acc2(int q) { return q < 4 ? q : (q == 4 ? 0 : (q == 5 ? 1 : 3)); }
 
 // OCC: workgroups per CU the kernel is built for (2: at most 256 registers); RD: depth of the weight ring in units (0: a whole chunk)
-// HALF: the tile's SECOND output row does not exist (last tile of an odd row count): the products that only feed it are skipped
-// (PH 0: M4; PH 2: the two into A3)
-template <int PH, int WM, int WN, int CIK, int NBUF, bool STATS, int OCC = 1, int RDP = 0, bool HALF = false>
+template <int PH, int WM, int WN, int CIK, int NBUF, bool STATS, int OCC = 1, int RDP = 0>
 __global__ __launch_bounds__(WM* WN * 64, OCC) void cconv_wino_kernel(const WinoArgs a) {
     constexpr int NT = WM * WN * 64;
     constexpr int TR = wino_tr<PH>();             // transformed patch rows per (channel, plane) = products per (channel, plane)
@@ -121,7 +118,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void cconv_wino_kernel(const Wino
     const int sg = bid / per, rem = bid - sg * per;
     const int v = rem >> 3;
     const int jt = sg * 8 + (rem & 7);
-    const int ft = a.ft0 + v / MB;
+    const int ft = v / MB;
     const int mblk = v - (v / MB) * MB;
     if (jt >= a.jtiles) return;
     const int j0 = jt * JT;
@@ -129,6 +126,9 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void cconv_wino_kernel(const Wino
     const bool ct_ok = ct < a.cotiles;
     const int m0 = 2 * ft;                        // transposed: first input row of the tile (raw patch rows m0 - 1 .. m0 + 2);
     const int rbase = PH == 2 ? 2 * m0 - 2 : m0 - 1;      // conv: first OUTPUT row (raw patch rows 2 m0 - 2 .. 2 m0 + 4)
+    // last tile of an odd row count: its SECOND output row does not exist, the products that only feed it are skipped (PH 0: M4;
+    // PH 2: the two into A3) -- a wave-uniform branch around 1 of 4 / 2 of 7 MFMAs per unit
+    const bool half_tile = PH != 1 && m0 + 1 >= (PH == 2 ? a.Fout : a.Fin);
 
     const int Cin = a.C0 + a.C1;
     const int nchunk = (Cin + CIK - 1) / CIK;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void cconv_wino_kernel(const Wino
                 constexpr int dummy = 0;
                 (void)dummy;
                 const int ai = PH == 2 ? wino_acc2(q) : q;
-                if (HALF && ai == 3) continue;            // feeds the missing second output row only
+                if (ai == 3 && half_tile) continue;       // feeds the missing second output row only
                 acc[ai][p3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[u % RD][q], b_cur[q], acc[ai][p3], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -435,34 +435,19 @@ int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
     b.jtiles = (a.J + JT - 1) / JT;
     // row tiles: pairs of input rows (transposed) / output rows (conv).  With an odd number of input rows the last pair's second
     // row does not exist and BOTH odd output rows of that tile (2 Fin - 1, 2 Fin + 1) lie outside the output: the odd-row phase
-    // skips the tile (a third of its work on the 5-row dec0, a fifth on dec1).  In the even-row phase and in the conv the last tile
-    // of an odd row count has ONE output row: it runs as its own launch of the HALF variant, which skips the products that only
-    // feed the missing row (1 of 4 / 2 of 7)
-    const int rows = PH == 2 ? a.Fout : a.Fin;
-    const int full = rows / 2, half = (PH != 1 && (rows & 1)) ? 1 : 0;
+    // skips the tile (a third of its work on the 5-row dec0, a fifth on dec1); in the even-row phase and in the conv that tile
+    // has ONE output row and skips the products that only feed the missing one (kernel: half_tile)
+    b.ftiles = PH == 2 ? (a.Fout + 1) / 2 : (PH == 1 ? a.Fin / 2 : (a.Fin + 1) / 2);
     b.mblocks = (a.cotiles + WM - 1) / WM;
+    if (b.ftiles == 0) return IDV_OK;
+    const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
+    if (nblk > 0x7fffffffLL) return IDV_EINVAL;
+    auto k = cconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS, OCC, RD>;
     // OCC 1: more than half a CU's LDS, i.e. one workgroup per CU whatever the register count says
     const size_t smem_req = OCC == 1 ? (smem > 84 * 1024 ? smem : 84 * 1024) : smem;
-    auto k = cconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS, OCC, RD, false>;
-    auto kh = cconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS, OCC, RD, true>;
     if (smem_req > 64 * 1024 &&
-        (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req) != hipSuccess ||
-         hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req) != hipSuccess))
-        return IDV_ELAUNCH;
-    static const bool use_half = [] { const char* e = getenv("IDV_WINO_HALF"); return !e || e[0] != '0'; }();
-    if (full + (use_half ? 0 : half) > 0) {
-        b.ft0 = 0;
-        b.ftiles = full + (use_half ? 0 : half);
-        const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
-        if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-        hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(WM * WN * 64), smem_req, st, b);
-    }
-    if (half && use_half) {
-        b.ft0 = full;
-        b.ftiles = 1;
-        const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.mblocks;
-        hipLaunchKernelGGL(kh, dim3((unsigned)nblk), dim3(WM * WN * 64), smem_req, st, b);
-    }
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_req) != hipSuccess) return IDV_ELAUNCH;
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(WM * WN * 64), smem_req, st, b);
     return idv_launch_status();
 }
 

@@ -1,5 +1,5 @@
 // Shared host-side state of the cooperative (spin-synchronised) recurrences: lstm_pers.hip, lstm_pers_f32.hip,
-// lstm_coop_f32.hip, lstm_bptt_coop_f32.hip, lstm_bptt_pers_f32.hip.  Implemented in lstm_pers.hip.
+// lstm_coop_f32.hip, lstm_stack2_f32.hip, lstm_bptt_coop_f32.hip, lstm_bptt_stack2_f32.hip.  Implemented in lstm_pers.hip.
 //
 // These kernels need ALL sibling workgroups resident at once (each spins on the others), so the library keeps three pieces
 // of per-device process state for them (and nothing else in the library is stateful):

@@ -6,7 +6,7 @@
  *   - every pointer is a DEVICE pointer (hipMalloc / torch.cuda memory) unless it says "host";
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it, never allocate device memory,
  *     never synchronise and are re-entrant across streams.  The ONLY process state the library keeps belongs to the
- *     cooperative recurrences (idv_lstm_rec_pers / _pers_f32 / _coop_f32, idv_lstm_bptt_coop / _pers): per device, the
+ *     cooperative recurrences (idv_lstm_rec_pers / _pers_f32 / _coop_f32 / idv_lstm_stack2_f32, idv_lstm_bptt_coop / _stack2): per device, the
  *     CU count, an event that orders cooperative launches of different streams, and a 256-byte host-mapped status word
  *     (see idv_coop_last_status);
  *   - return value: 0 ok, -1 invalid argument, -2 launch failure, -3 (IDV_ECOOP) an EARLIER cooperative recurrence ran into
