@@ -303,6 +303,261 @@ __global__ void wgrad_unpack_gauss_kernel(const float* __restrict__ part, long l
     }
 }
 
+
+// ---- Winograd form of the frequency taps of the weight gradient (round 4) --------------------------------------------------------
+// G[kf] = sum_fs S[fs] (x) L[2 fs + kf - 2] for kf = 0..4 spends ten products per PAIR of S rows (c0 = S[2 fp], c1 = S[2 fp + 1]; with
+// r_k = L[4 fp - 2 + k]:  G0 += c0 r0 + c1 r2,  G2 += c0 r2 + c1 r4,  G4 += c0 r4 + c1 r6,  G1 += c0 r1 + c1 r3,  G3 += c0 r3 + c1 r5).
+// The even taps are the gradient of an F(2,3) correlation with respect to its three taps, the odd taps that of an F(2,2) one; by
+// the transposition principle they need the same 4 + 3 products as the forward transforms of cgemm_wino.hip:
+//   even:  p1 = c0 (r0 - r4)   p2 = (c0 + c1)(r2 + r4)   p3 = (c0 - c1)(r4 - r2)   p4 = c1 (r6 - r2)
+//          G0 = p1 + (p2 + p3)/2     G2 = (p2 - p3)/2     G4 = (p2 + p3)/2 + p4
+//   odd:   q1 = c0 (r1 - r3)   q2 = (c0 + c1) r3         q3 = c1 (r5 - r3)           G1 = q1 + q2     G3 = q2 + q3
+// -- 7 instead of 10 MFMA products per pair of rows and time tap.  The products are accumulated over all row pairs and columns;
+// the tap combination is linear and happens ONCE, in the unpack kernel.  Two kernels (PHW 0: even taps, 4 variants x 2 time taps
+// = 8 accumulator tiles per wave; PHW 1: odd taps, 6 tiles) so that both run at two workgroups per CU.  Both operands are
+// transformed at the LDS write: S variants (c0, c0 + c1, c0 - c1, c1), L rows as above.  LDS layouts [variant][plane][col] /
+// [row][plane][col] keep the odd plane pitch the conflict-free ds_read_b32 pattern needs.
+constexpr int WW_JT = 16, WW_PS = WW_JT + 3, WW_MS = 128, WW_ML = 32;
+
+template <int PHW> __device__ __forceinline__ int ww_la(int r) { return PHW == 0 ? (r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 4 : 6))) : (r == 0 ? 1 : (r == 1 ? 3 : 5)); }
+template <int PHW> __device__ __forceinline__ int ww_lb(int r) { return PHW == 0 ? (r == 0 ? 4 : (r == 1 ? 4 : 2)) : 3; }
+template <int PHW> __device__ __forceinline__ float ww_cb(int r) { return PHW == 0 ? (r == 1 ? 1.f : -1.f) : (r == 1 ? 0.f : -1.f); }
+
+template <int PHW, int OCC>
+__global__ __launch_bounds__(256, OCC) void wgrad_wino_kernel(const WgradArgs a) {
+    constexpr int NV = PHW == 0 ? 4 : 3;                      // S variants = transformed L rows = products per time tap
+    constexpr int KT = 2;
+    constexpr int Q4 = WW_JT / 4;
+    constexpr int S_SLOTS = WW_MS * Q4;                       // raw float4 slots of the S tile (each loads both rows of the pair)
+    constexpr int L_SLOTS = NV * WW_ML * Q4;                  // transformed float4 slots of the L tile
+    constexpr int NS4 = (S_SLOTS + 255) / 256, NL4 = (L_SLOTS + 255) / 256;
+    constexpr int L_HALO = NV * WW_ML * 2;                    // columns j0 - 1 and j0 + JT of every transformed row
+    static_assert(L_HALO <= 256, "one halo element per thread");
+    __shared__ float Ssm[NV * WW_MS * WW_PS];
+    __shared__ float Lsm[NV * WW_ML * WW_PS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int split = blockIdx.x, ts = blockIdx.y;
+    int tl = blockIdx.z, prod = 0;
+    if (a.nprod > 1) {
+        prod = tl / a.tilesL;
+        tl -= prod * a.tilesL;
+    }
+    const float* __restrict__ Sg = prod == 0 ? a.S : (prod == 1 ? a.S1 : a.S2);
+    const float* __restrict__ Lg = prod == 0 ? a.L : (prod == 1 ? a.L1 : a.L2);
+    const int sp0 = ts * WW_MS, lp0 = tl * WW_ML;
+    const int FP = (a.Fs + 1) >> 1;                           // row pairs
+    const long long s0 = (long long)split * a.steps_total / a.nsplit_bal, s1 = (long long)(split + 1) * a.steps_total / a.nsplit_bal;
+    const int g0 = (int)s0, nsteps = (int)(s1 - s0);
+
+    f32x16 acc[NV][KT];
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.f;
+
+    f32x4 s0r[NS4], s1r[NS4], lar[NL4], lbr[NL4];
+    float har = 0.f, hbr = 0.f;
+
+    // branch-free staging as wgrad_kernel: unconditional loads (invalid slots read element 0), masks at the LDS write
+    auto load_step = [&](int step) {
+        const int g = g0 + step;
+        const int jt = g / FP, fp = g - jt * FP;
+        const int j0 = jt * WW_JT;
+#pragma unroll
+        for (int i = 0; i < NS4; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int sp = sp0 + row, j = j0 + 4 * q;
+            const bool ok = (e < S_SLOTS) && (sp < a.Sp) && (j < a.J);
+            const bool ok1 = ok && (2 * fp + 1 < a.Fs);
+            const size_t o0 = ok ? ((size_t)sp * a.Fs + 2 * fp) * a.JpS + j : 0;
+            const size_t o1 = ok1 ? o0 + a.JpS : 0;
+            s0r[i] = *(const f32x4*)(Sg + o0);
+            s1r[i] = *(const f32x4*)(Sg + o1);
+        }
+#pragma unroll
+        for (int i = 0; i < NL4; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int r = row / WW_ML, pl = row - r * WW_ML;
+            const int lp = lp0 + pl, j = j0 + 4 * q;
+            const int fa = 4 * fp - 2 + ww_la<PHW>(r), fb = 4 * fp - 2 + ww_lb<PHW>(r);
+            const bool ok = (e < L_SLOTS) && (lp < a.Lp) && (j < a.J);
+            const bool oka = ok && fa >= 0 && fa < a.Fl, okb = ok && ww_cb<PHW>(r) != 0.f && fb >= 0 && fb < a.Fl;
+            lar[i] = *(const f32x4*)(Lg + (oka ? ((size_t)lp * a.Fl + fa) * a.JpL + j : 0));
+            lbr[i] = *(const f32x4*)(Lg + (okb ? ((size_t)lp * a.Fl + fb) * a.JpL + j : 0));
+        }
+        {
+            const int e = tid;
+            const int row = e >> 1, side = e & 1;
+            const int r = row / WW_ML, pl = row - r * WW_ML;
+            const int lp = lp0 + pl;
+            const int fa = 4 * fp - 2 + ww_la<PHW>(r < NV ? r : 0), fb = 4 * fp - 2 + ww_lb<PHW>(r < NV ? r : 0);
+            const int j = side ? j0 + WW_JT : j0 - 1;
+            const bool ok = (e < L_HALO) && (lp < a.Lp) && (j >= 0) && (j < a.J);
+            const bool oka = ok && fa >= 0 && fa < a.Fl, okb = ok && ww_cb<PHW>(r < NV ? r : 0) != 0.f && fb >= 0 && fb < a.Fl;
+            har = Lg[oka ? ((size_t)lp * a.Fl + fa) * a.JpL + j : 0];
+            hbr = Lg[okb ? ((size_t)lp * a.Fl + fb) * a.JpL + j : 0];
+        }
+    };
+    auto store_step = [&](int step) {
+        const int g = g0 + step;
+        const int jt = g / FP, fp = g - jt * FP;
+        const int j0 = jt * WW_JT;
+#pragma unroll
+        for (int i = 0; i < NS4; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int sp = sp0 + row, j = j0 + 4 * q;
+            const bool ok = (sp < a.Sp), ok1 = ok && (2 * fp + 1 < a.Fs);
+            if (e < S_SLOTS) {
+                float* d = Ssm + row * WW_PS + 4 * q;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float c0 = (ok && j + c < a.J) ? s0r[i][c] : 0.f, c1 = (ok1 && j + c < a.J) ? s1r[i][c] : 0.f;
+                    d[c] = c0;
+                    d[WW_MS * WW_PS + c] = c0 + c1;
+                    if (PHW == 0) {
+                        d[2 * WW_MS * WW_PS + c] = c0 - c1;
+                        d[3 * WW_MS * WW_PS + c] = c1;
+                    } else {
+                        d[2 * WW_MS * WW_PS + c] = c1;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NL4; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / Q4, q = e - row * Q4;
+            const int r = row / WW_ML, pl = row - r * WW_ML;
+            const int lp = lp0 + pl, j = j0 + 4 * q;
+            const int fa = 4 * fp - 2 + ww_la<PHW>(r), fb = 4 * fp - 2 + ww_lb<PHW>(r);
+            const bool ok = (lp < a.Lp);
+            const bool oka = ok && fa >= 0 && fa < a.Fl, okb = ok && ww_cb<PHW>(r) != 0.f && fb >= 0 && fb < a.Fl;
+            if (e < L_SLOTS) {
+                float* d = Lsm + row * WW_PS + 1 + 4 * q;                // LDS column c = j - j0 + 1
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float va = (oka && j + c < a.J) ? lar[i][c] : 0.f, vb = (okb && j + c < a.J) ? lbr[i][c] : 0.f;
+                    d[c] = va + ww_cb<PHW>(r) * vb;
+                }
+            }
+        }
+        {
+            const int e = tid;
+            const int row = e >> 1, side = e & 1;
+            const int r = row / WW_ML, pl = row - r * WW_ML;
+            const int lp = lp0 + pl;
+            const int fa = 4 * fp - 2 + ww_la<PHW>(r < NV ? r : 0), fb = 4 * fp - 2 + ww_lb<PHW>(r < NV ? r : 0);
+            const int j = side ? j0 + WW_JT : j0 - 1;
+            const bool ok = (lp < a.Lp) && (j >= 0) && (j < a.J);
+            const bool oka = ok && fa >= 0 && fa < a.Fl, okb = ok && ww_cb<PHW>(r < NV ? r : 0) != 0.f && fb >= 0 && fb < a.Fl;
+            if (e < L_HALO) Lsm[row * WW_PS + (side ? WW_JT + 1 : 0)] = (oka ? har : 0.f) + ww_cb<PHW>(r < NV ? r : 0) * (okb ? hbr : 0.f);
+        }
+    };
+
+    if (nsteps > 0) load_step(0);
+    for (int step = 0; step < nsteps; ++step) {
+        store_step(step);
+        __syncthreads();
+        if (step + 1 < nsteps) load_step(step + 1);
+        const float* As = Ssm + (wm * 32 + l31) * WW_PS + half;
+        const float* Bs = Lsm + l31 * WW_PS + half + 1 + a.dt0;
+        float av[NV], bv[NV][KT], an[NV], bn[NV][KT];
+        auto lds_load = [&](int ks, float (&ao)[NV], float (&bo)[NV][KT]) {
+            const int col = 2 * ks;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                ao[q] = As[q * WW_MS * WW_PS + col];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) bo[q][kt] = Bs[q * WW_ML * WW_PS + col + kt];
+            }
+        };
+        lds_load(0, av, bv);
+#pragma unroll 2
+        for (int ks = 0; ks < WW_JT / 2; ++ks) {
+            lds_load(ks + 1 < WW_JT / 2 ? ks + 1 : ks, an, bn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int q = 0; q < NV; ++q) acc[q][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q][kt], acc[q][kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                av[q] = an[q];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) bv[q][kt] = bn[q][kt];
+            }
+        }
+        __syncthreads();
+    }
+
+    // partial product tiles -> workspace: [product][even: nsplit x 8 planes | odd: nsplit x 6 planes][SpPad][LpPad]
+    const size_t plane = (size_t)a.SpPad * a.LpPad;
+    float* P = a.part + (size_t)prod * a.prod_stride + (PHW == 0 ? 0 : (size_t)a.nsplit_bal * 8 * plane) + (size_t)split * (2 * NV) * plane;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int sp = sp0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int lp = lp0 + l31;
+                P[((size_t)(q * KT + kt)) * plane + (size_t)sp * a.LpPad + lp] = acc[q][kt][r];
+            }
+}
+
+// the tap (kf, kt) of product `P0` (one Gauss product's region) from the 8 + 6 partial product planes of the Winograd kernels
+__device__ __forceinline__ double wgrad_wino_tap(const float* __restrict__ P0, int nsplit, size_t plane, size_t elem, int kf, int kt) {
+    double e[4] = {0, 0, 0, 0};
+    if ((kf & 1) == 0) {
+        for (int sidx = 0; sidx < nsplit; ++sidx) {
+            const float* P = P0 + (size_t)sidx * 8 * plane + elem;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] += P[(size_t)(q * 2 + kt) * plane];
+        }
+        return kf == 0 ? e[0] + 0.5 * (e[1] + e[2]) : (kf == 2 ? 0.5 * (e[1] - e[2]) : 0.5 * (e[1] + e[2]) + e[3]);
+    }
+    const float* Q0 = P0 + (size_t)nsplit * 8 * plane;
+    for (int sidx = 0; sidx < nsplit; ++sidx) {
+        const float* P = Q0 + (size_t)sidx * 6 * plane + elem;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) e[q] += P[(size_t)(q * 2 + kt) * plane];
+    }
+    return kf == 1 ? e[0] + e[1] : e[1] + e[2];
+}
+
+__global__ void wgrad_unpack_gauss_wino_kernel(const float* __restrict__ part, long long prod_stride, int nsplit, int SpPad, int LpPad,
+                                               int Cout, int Cx, int Cin_total, int ci_off, int transposed, float* __restrict__ dw_re,
+                                               float* __restrict__ dw_im) {
+    const int Cs = transposed ? Cx : Cout, Cl = transposed ? Cout : Cx;
+    const long long n = (long long)Cs * Cl * 10;
+    const size_t plane = (size_t)SpPad * LpPad;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const int lc = (int)(idx % Cl);
+        const int sc = (int)((idx / Cl) % Cs);
+        const int tap = (int)(idx / ((long long)Cl * Cs));
+        const int kf = tap >> 1, kt = tap & 1;
+        const size_t elem = (size_t)sc * LpPad + lc;
+        const double p1 = wgrad_wino_tap(part, nsplit, plane, elem, kf, kt);
+        const double p2 = wgrad_wino_tap(part + prod_stride, nsplit, plane, elem, kf, kt);
+        const double p3 = wgrad_wino_tap(part + 2 * prod_stride, nsplit, plane, elem, kf, kt);
+        const double dwr = p1 + p2;
+        const double dwi = transposed ? (p3 + p2 - p1) : (p1 - p2 - p3);
+        const int co = transposed ? lc : sc, ci = ci_off + (transposed ? sc : lc);
+        const size_t o = transposed ? (((size_t)ci * Cout + co) * 10 + tap) : (((size_t)co * Cin_total + ci) * 10 + tap);
+        dw_re[o] = (float)dwr;
+        dw_im[o] = (float)dwi;
+    }
+}
+
 // out[rowmap(m)][k] (+)= sum_splits part[split][0][m][k];  rowmap: 0 identity, 1 LSTM gate order (colp -> g*H + u)
 __global__ void wgrad_unpack_plain_kernel(const float* __restrict__ part, int nsplit, int SpPad, int LpPad, int M, int K,
                                           int ldo, int rowmap, int H, int accumulate, float* __restrict__ out) {
@@ -513,11 +768,24 @@ extern "C" int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const 
 // ---- Gauss form: entry points -----------------------------------------------------------------------------------------------
 namespace {
 const bool WGRAD_GAUSS = [] { const char* e = getenv("IDV_WGRAD_GAUSS"); return !e || e[0] != '0'; }();
+// Winograd form of the frequency taps (wgrad_wino_kernel): IDV_WGRAD_WINO=0 keeps the ten-product kernel.  Per layer at B = 32
+// (tests/tools/wgrad_layers_probe.py, ten-product -> Winograd): enc2 3.67 -> 3.44 ms, enc3 3.46 -> 3.24, enc4 3.51 -> 3.37, dec1
+// 6.81 -> 6.65, dec2 6.68 -> 6.15, dec3 7.24 -> 6.51, dec4 3.94 -> 3.85; with five S rows (three pairs, the last half empty) it
+// LOSES (enc5 3.85 -> 3.94, dec0 7.38 -> 7.52), so layers with fewer than 8 S rows keep the ten-product kernel.  The gain is far
+// below the 30 % fewer MFMAs: the kernel is bound by its staging (both operands transformed at the LDS write, one LDS buffer
+// between two barriers per 16-column step), not by the matrix pipe.
+const bool WGRAD_WINO = [] { const char* e = getenv("IDV_WGRAD_WINO"); return !e || e[0] != '0'; }();
+inline bool wgrad_wino_for(int Fs) {
+    static const int min_rows = [] { const char* e = getenv("IDV_WGRAD_WINO_MINF"); return e ? atoi(e) : 8; }();
+    return WGRAD_WINO && Fs >= min_rows;
+}
 struct GaussPlan { Plan p; long long prod_stride, part_floats, s_comb, l_comb; };
 inline GaussPlan gauss_plan(int Cs, int Cl, int Fs, int Fl, int J, int JpS, int JpL) {
     GaussPlan g;
-    g.p = make_plan_rounds(Cs, Cl, J, CONV_MS, CONV_ML, CONV_JT, 3, 2, Fs);
-    g.prod_stride = (long long)g.p.nsplit * 10 * g.p.SpPad * g.p.LpPad;
+    // Winograd form: a step is a PAIR of S rows, 8 + 6 partial product planes per split instead of 10 tap planes
+    const bool wino = wgrad_wino_for(Fs);
+    g.p = make_plan_rounds(Cs, Cl, J, CONV_MS, CONV_ML, CONV_JT, 3, 2, wino ? (Fs + 1) / 2 : Fs);
+    g.prod_stride = (long long)g.p.nsplit * (wino ? 14 : 10) * g.p.SpPad * g.p.LpPad;
     g.part_floats = 3 * g.prod_stride;
     g.s_comb = ((long long)Cs * Fs * JpS + 63) / 64 * 64;
     g.l_comb = ((long long)Cl * Fl * JpL + 63) / 64 * 64;
@@ -586,6 +854,14 @@ extern "C" int idv_cconv2d_bwd_weight_gauss(const float* x, int Cx, int ci_off, 
     a.part = work; a.SpPad = g.p.SpPad; a.LpPad = g.p.LpPad; a.jtiles = g.p.jtiles;
     a.nsplit_bal = g.p.nsplit; a.steps_total = (long long)g.p.jtiles * a.Fs;
     const dim3 grid(g.p.nsplit, g.p.tilesS, 3 * g.p.tilesL);
+    if (wgrad_wino_for(a.Fs)) {
+        a.steps_total = (long long)g.p.jtiles * ((a.Fs + 1) / 2);
+        hipLaunchKernelGGL((wgrad_wino_kernel<0, 2>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((wgrad_wino_kernel<1, 2>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(wgrad_unpack_gauss_wino_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work,
+                           g.prod_stride, g.p.nsplit, g.p.SpPad, g.p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
+        return idv_launch_status();
+    }
     hipLaunchKernelGGL((wgrad_kernel<5, 2, 1, 1, 4, 1, CONV_JT, 2>), grid, dim3(256), 0, st, a);
     hipLaunchKernelGGL(wgrad_unpack_gauss_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work, g.prod_stride,
                        g.p.nsplit, g.p.SpPad, g.p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);

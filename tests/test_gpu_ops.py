@@ -181,6 +181,47 @@ def test_cconv_gauss_stats_and_adjoint(ops):
         assert relerr(d1.tensor5().cpu(), d0.tensor5().cpu()) < 1e-5
 
 
+def test_cconv_wino_stats_and_adjoint(ops):
+    """Training forms of the Winograd kernels at served widths: train-mode moment sums (STATS variants) and the adjoint /
+    data-gradient operators (adjoint of a conv = transposed conv and vice versa, `conj` packing) against cgemm_gauss_kernel."""
+    g = torch.Generator().manual_seed(9)
+    dev = "cuda"
+    keep, keep_log = ops.WINO, ops.LAUNCH_LOG
+    try:
+        for transposed, cin, cout, F in ((True, 24, 72, 9), (False, 128, 136, 17), (True, 136, 128, 6)):
+            x = torch.randn(3, cin, F, 37, 2, generator=g)
+            shape = (cin, cout, 5, 2) if transposed else (cout, cin, 5, 2)
+            wr, wi = (torch.randn(shape, generator=g) * 0.1).to(dev), (torch.randn(shape, generator=g) * 0.1).to(dev)
+            br, bi = torch.randn(cout, generator=g).to(dev), torch.randn(cout, generator=g).to(dev)
+            xp = ops.Planar.from_tensor5(x.to(dev), 38)
+            ops.WINO = True
+            g3 = ops.pack_cconv_gauss(wr, wi, br, bi, None, transposed=transposed)
+            res = {}
+            for wino in (False, True):
+                ops.WINO = wino
+                ops.LAUNCH_LOG = []
+                st = torch.zeros(cout, 5, dtype=torch.float64, device=dev)
+                y = ops.cconv2d(xp, None, None, cout, transposed=transposed, stats=st, gauss=g3)
+                assert bool([c for c, *_ in ops.LAUNCH_LOG if c >= ops.WINO_CFG]) == wino
+                res[wino] = (y.tensor5().cpu(), st.cpu())
+            assert relerr(res[True][0], res[False][0]) < 5e-6
+            assert relerr(res[True][1], res[False][1]) < 1e-5
+            # adjoint: dy has the OUTPUT geometry; the data gradient is the other operator with conjugate-transposed weights
+            dy = ops.Planar.from_tensor5(torch.randn(3, cout, y.F, 37, 2, generator=g).to(dev), 38)
+            ops.WINO = True
+            ga = ops.pack_cconv_gauss(wr, wi, None, None, None, adjoint_of=(cin, cout, cout, not transposed))
+            d = {}
+            for wino in (False, True):
+                ops.WINO = wino
+                ops.LAUNCH_LOG = []
+                d[wino] = ops.cconv_dgrad(dy, None, None, cin, transposed, True, gauss=ga).tensor5().cpu()
+                served = bool(ops.L.lib().idv_cconv_wino_supported(int(not transposed), cout, 0, cin, dy.F))
+                assert bool([c for c, *_ in ops.LAUNCH_LOG if c >= ops.WINO_CFG]) == (wino and served)
+            assert relerr(d[True], d[False]) < 5e-6
+    finally:
+        ops.WINO, ops.LAUNCH_LOG = keep, keep_log
+
+
 @pytest.mark.parametrize("ns,B0,c0,c1,cout,F,T", [(2, 3, 8, 8, 12, 9, 30), (5, 2, 16, 16, 40, 17, 21), (3, 1, 4, 6, 4, 33, 45)])
 def test_cconv_gauss_skip_half_once(ops, ns, B0, c0, c1, cout, F, T):
     """Repeated skips (pvae_module.py:2563-2567): the skip half of the transposed conv computed once per utterance and added in

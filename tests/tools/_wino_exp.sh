@@ -1,7 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r04n
-timeout -k 10 400 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "wino or gauss" 2>&1 | tail -2
-python tests/tools/wino_layers_probe.py 64 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r04n/wino_cfgs.log
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt > gpurun_out/r04n/bench_f32.json 2> gpurun_out/r04n/bench_f32.err; python3 -c "
-import json;d=json.load(open('gpurun_out/r04n/bench_f32.json'));print(d['value'],d['ms_per_step'],d['roofline']['traffic'])"
+mkdir -p gpurun_out/r04o
+timeout -k 10 600 python -m pytest tests/test_gpu_backward.py -q -m gpu -x -k "wgrad or conv_block_grads" 2>&1 | tail -3
+timeout -k 10 300 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "wino" 2>&1 | tail -2
+for w in 1 0; do IDV_WGRAD_WINO=$w python tests/tools/wgrad_layers_probe.py 32 2>&1 | grep -v amdgpu.ids | sed "s/^/[wino=$w] /" | tee -a gpurun_out/r04o/wgrad_layers.log; done
