@@ -317,14 +317,18 @@ __global__ void wgrad_unpack_gauss_kernel(const float* __restrict__ part, long l
 // = 8 accumulator tiles per wave; PHW 1: odd taps, 6 tiles) so that both run at two workgroups per CU.  Both operands are
 // transformed at the LDS write: S variants (c0, c0 + c1, c0 - c1, c1), L rows as above.  LDS layouts [variant][plane][col] /
 // [row][plane][col] keep the odd plane pitch the conflict-free ds_read_b32 pattern needs.
-constexpr int WW_JT = 16, WW_PS = WW_JT + 3, WW_MS = 128, WW_ML = 32;
+constexpr int WW_MS = 128, WW_ML = 32;
 
 template <int PHW> __device__ __forceinline__ int ww_la(int r) { return PHW == 0 ? (r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 4 : 6))) : (r == 0 ? 1 : (r == 1 ? 3 : 5)); }
 template <int PHW> __device__ __forceinline__ int ww_lb(int r) { return PHW == 0 ? (r == 0 ? 4 : (r == 1 ? 4 : 2)) : 3; }
 template <int PHW> __device__ __forceinline__ float ww_cb(int r) { return PHW == 0 ? (r == 1 ? 1.f : -1.f) : (r == 1 ? 0.f : -1.f); }
 
-template <int PHW, int OCC>
+// WW_JT columns per step (16 or 32).  The S tile is kept RAW in the LDS (the two rows of the pair); the variants c0 + c1, c0 - c1
+// are formed in registers behind the LDS read (two VALU instructions per k-step instead of 16 instead of 8 LDS writes per staged
+// slot and two more LDS reads per k-step); the L rows are transformed at the LDS write.
+template <int PHW, int OCC, int WW_JT>
 __global__ __launch_bounds__(256, OCC) void wgrad_wino_kernel(const WgradArgs a) {
+    constexpr int WW_PS = WW_JT + 3;
     constexpr int NV = PHW == 0 ? 4 : 3;                      // S variants = transformed L rows = products per time tap
     constexpr int KT = 2;
     constexpr int Q4 = WW_JT / 4;
@@ -332,9 +336,9 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wino_kernel(const WgradArgs a)
     constexpr int L_SLOTS = NV * WW_ML * Q4;                  // transformed float4 slots of the L tile
     constexpr int NS4 = (S_SLOTS + 255) / 256, NL4 = (L_SLOTS + 255) / 256;
     constexpr int L_HALO = NV * WW_ML * 2;                    // columns j0 - 1 and j0 + JT of every transformed row
-    static_assert(L_HALO <= 256, "one halo element per thread");
-    __shared__ float Ssm[NV * WW_MS * WW_PS];
-    __shared__ float Lsm[NV * WW_ML * WW_PS];
+    static_assert(L_HALO <= 256 && (WW_PS & 1) == 1, "one halo element per thread; odd LDS pitch");
+    __shared__ float Ssm[2 * WW_MS * WW_PS];                  // [row of the pair][plane][col]
+    __shared__ float Lsm[NV * WW_ML * WW_PS];                 // [transformed row][plane][col]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -419,15 +423,8 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wino_kernel(const WgradArgs a)
                 float* d = Ssm + row * WW_PS + 4 * q;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float c0 = (ok && j + c < a.J) ? s0r[i][c] : 0.f, c1 = (ok1 && j + c < a.J) ? s1r[i][c] : 0.f;
-                    d[c] = c0;
-                    d[WW_MS * WW_PS + c] = c0 + c1;
-                    if (PHW == 0) {
-                        d[2 * WW_MS * WW_PS + c] = c0 - c1;
-                        d[3 * WW_MS * WW_PS + c] = c1;
-                    } else {
-                        d[2 * WW_MS * WW_PS + c] = c1;
-                    }
+                    d[c] = (ok && j + c < a.J) ? s0r[i][c] : 0.f;
+                    d[WW_MS * WW_PS + c] = (ok1 && j + c < a.J) ? s1r[i][c] : 0.f;
                 }
             }
         }
@@ -469,32 +466,36 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wino_kernel(const WgradArgs a)
         if (step + 1 < nsteps) load_step(step + 1);
         const float* As = Ssm + (wm * 32 + l31) * WW_PS + half;
         const float* Bs = Lsm + l31 * WW_PS + half + 1 + a.dt0;
-        float av[NV], bv[NV][KT], an[NV], bn[NV][KT];
-        auto lds_load = [&](int ks, float (&ao)[NV], float (&bo)[NV][KT]) {
+        float c0v, c1v, bv[NV][KT], c0n, c1n, bn[NV][KT];
+        auto lds_load = [&](int ks, float& c0, float& c1, float (&bo)[NV][KT]) {
             const int col = 2 * ks;
+            c0 = As[col];
+            c1 = As[WW_MS * WW_PS + col];
 #pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                ao[q] = As[q * WW_MS * WW_PS + col];
+            for (int q = 0; q < NV; ++q)
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) bo[q][kt] = Bs[q * WW_ML * WW_PS + col + kt];
-            }
         };
-        lds_load(0, av, bv);
+        lds_load(0, c0v, c1v, bv);
 #pragma unroll 2
         for (int ks = 0; ks < WW_JT / 2; ++ks) {
-            lds_load(ks + 1 < WW_JT / 2 ? ks + 1 : ks, an, bn);
+            lds_load(ks + 1 < WW_JT / 2 ? ks + 1 : ks, c0n, c1n, bn);
             __builtin_amdgcn_sched_barrier(0);
+            float av[NV];
+            av[0] = c0v;
+            av[1] = c0v + c1v;
+            if (PHW == 0) { av[2] = c0v - c1v; av[NV - 1] = c1v; } else { av[NV - 1] = c1v; }
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int q = 0; q < NV; ++q) acc[q][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q][kt], acc[q][kt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            c0v = c0n;
+            c1v = c1n;
 #pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                av[q] = an[q];
+            for (int q = 0; q < NV; ++q)
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) bv[q][kt] = bn[q][kt];
-            }
         }
         __syncthreads();
     }
@@ -769,12 +770,19 @@ extern "C" int idv_cconv2d_bwd_weight(const float* x, int Cx, int ci_off, const 
 namespace {
 const bool WGRAD_GAUSS = [] { const char* e = getenv("IDV_WGRAD_GAUSS"); return !e || e[0] != '0'; }();
 // Winograd form of the frequency taps (wgrad_wino_kernel): IDV_WGRAD_WINO=0 keeps the ten-product kernel.  Per layer at B = 32
-// (tests/tools/wgrad_layers_probe.py, ten-product -> Winograd): enc2 3.67 -> 3.44 ms, enc3 3.46 -> 3.24, enc4 3.51 -> 3.37, dec1
-// 6.81 -> 6.65, dec2 6.68 -> 6.15, dec3 7.24 -> 6.51, dec4 3.94 -> 3.85; with five S rows (three pairs, the last half empty) it
-// LOSES (enc5 3.85 -> 3.94, dec0 7.38 -> 7.52), so layers with fewer than 8 S rows keep the ten-product kernel.  The gain is far
-// below the 30 % fewer MFMAs: the kernel is bound by its staging (both operands transformed at the LDS write, one LDS buffer
-// between two barriers per 16-column step), not by the matrix pipe.
+// (tests/tools/wgrad_layers_probe.py, ten-product -> Winograd with 32-column steps): enc2 3.67 -> 3.08 ms, enc3 3.46 -> 3.02, enc4
+// 3.51 -> 3.15, dec1 6.81 -> 6.47, dec2 6.68 -> 5.73, dec3 7.24 -> 5.77, dec4 3.94 -> 3.40; with five S rows (three pairs, the last
+// half empty) it does not pay (enc5 3.85 -> 3.88, dec0 7.38 -> 7.45), so layers with fewer than 8 S rows keep the ten-product
+// kernel.  All layers of the DCCRN-CL step: 49.9 -> 45.3 ms.  The gain stays below the 30 % fewer MFMAs because the kernel is
+// bound as much by its staging (one LDS buffer between two barriers per step) as by the matrix pipe: the first version, with all
+// four S variants written to the LDS and 16-column steps, gained 4 % only.
 const bool WGRAD_WINO = [] { const char* e = getenv("IDV_WGRAD_WINO"); return !e || e[0] != '0'; }();
+// columns per step of the Winograd kernels: 32 (half the barriers per MFMA; the even-tap kernel then sits at 256 registers with 11
+// spilled: still faster -- all layers 47.05 -> 45.31 ms at B = 32); IDV_WGRAD_WINO_JT=16: 16-column steps
+inline int wgrad_wino_jt() {
+    static const int v = [] { const char* e = getenv("IDV_WGRAD_WINO_JT"); return (e && atoi(e) == 16) ? 16 : 32; }();
+    return v;
+}
 inline bool wgrad_wino_for(int Fs) {
     static const int min_rows = [] { const char* e = getenv("IDV_WGRAD_WINO_MINF"); return e ? atoi(e) : 8; }();
     return WGRAD_WINO && Fs >= min_rows;
@@ -784,7 +792,7 @@ inline GaussPlan gauss_plan(int Cs, int Cl, int Fs, int Fl, int J, int JpS, int 
     GaussPlan g;
     // Winograd form: a step is a PAIR of S rows, 8 + 6 partial product planes per split instead of 10 tap planes
     const bool wino = wgrad_wino_for(Fs);
-    g.p = make_plan_rounds(Cs, Cl, J, CONV_MS, CONV_ML, CONV_JT, 3, 2, wino ? (Fs + 1) / 2 : Fs);
+    g.p = make_plan_rounds(Cs, Cl, J, CONV_MS, CONV_ML, wino ? wgrad_wino_jt() : CONV_JT, 3, 2, wino ? (Fs + 1) / 2 : Fs);
     g.prod_stride = (long long)g.p.nsplit * (wino ? 14 : 10) * g.p.SpPad * g.p.LpPad;
     g.part_floats = 3 * g.prod_stride;
     g.s_comb = ((long long)Cs * Fs * JpS + 63) / 64 * 64;
@@ -856,8 +864,13 @@ extern "C" int idv_cconv2d_bwd_weight_gauss(const float* x, int Cx, int ci_off, 
     const dim3 grid(g.p.nsplit, g.p.tilesS, 3 * g.p.tilesL);
     if (wgrad_wino_for(a.Fs)) {
         a.steps_total = (long long)g.p.jtiles * ((a.Fs + 1) / 2);
-        hipLaunchKernelGGL((wgrad_wino_kernel<0, 2>), grid, dim3(256), 0, st, a);
-        hipLaunchKernelGGL((wgrad_wino_kernel<1, 2>), grid, dim3(256), 0, st, a);
+        if (wgrad_wino_jt() == 32) {
+            hipLaunchKernelGGL((wgrad_wino_kernel<0, 2, 32>), grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((wgrad_wino_kernel<1, 2, 32>), grid, dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((wgrad_wino_kernel<0, 2, 16>), grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((wgrad_wino_kernel<1, 2, 16>), grid, dim3(256), 0, st, a);
+        }
         hipLaunchKernelGGL(wgrad_unpack_gauss_wino_kernel, dim3(grid_for((long long)Cout * Cx * 10)), dim3(256), 0, st, work,
                            g.prod_stride, g.p.nsplit, g.p.SpPad, g.p.LpPad, Cout, Cx, Cin_total, ci_off, transposed, dw_re, dw_im);
         return idv_launch_status();
