@@ -379,8 +379,8 @@ def kernel_name(cfg_id):
         if tr:                                # the two phase kernels of a transposed-conv layer (+ their half-tile variants)
             a, b = kernel_parts(cfg_id)
             return a.replace("((anonymous namespace)::WinoArgs)", "") + " + " + b.replace("void (anonymous namespace)::cconv_wino_kernel", "")
-        return (f"void (anonymous namespace)::cconv_wino_kernel<2, {d[0]}, {d[1]}, {d[2]}, 3, false, 1, {3 * int(d[2]) // 2}>"
-                "((anonymous namespace)::WinoArgs)")
+        tail = "2, 3, false, 2, 3" if d[2] == "2" else f"{d[2]}, 3, false, 1, {3 * int(d[2]) // 2}"      # two channels per chunk: 2 workgroups / CU
+        return f"void (anonymous namespace)::cconv_wino_kernel<2, {d[0]}, {d[1]}, {tail}>((anonymous namespace)::WinoArgs)"
     if 3000000 <= cfg_id < 4000000:       # idv_cconv_gauss_config digits 3 MODE WM WN FO_T JC_W OCC
         d = str(cfg_id)
         occ = int(d[6])

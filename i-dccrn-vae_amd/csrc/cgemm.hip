@@ -161,6 +161,15 @@ extern "C" int idv_pw_gemm(const float* x, int K, const float* wfrag, const floa
     // four row-tile pairs x ONE column group per workgroup where the rows come in whole 256-row blocks (the LSTM input
     // projections: M = 8H): a 72-column patch per workgroup instead of 136, as for the wide transposed conv (cgemm_gauss.hip):
     // M = 1024 / 3072 / 6144, K = 1280, B = 64: 1.20 / 3.08 / 5.88 -> 1.16 / 2.97 / 5.60 ms.  IDV_PW_CFG=7 keeps 2 x 2.
+    // experiments: 16 / 32 planes per K chunk (a quarter of the barriers per MFMA); K in whole chunks only
+    if ((pwcfg == 16 || pwcfg == 32) && a.Mtiles % 8 == 0 && K % pwcfg == 0) {
+        if (pwcfg == 16) {
+            if (swap) return launch_cfg<IDV_PW, 4, 1, 2, 1, 2, 16, true, false>(a, st);
+            return launch_cfg<IDV_PW, 4, 1, 2, 1, 2, 16, false, false>(a, st);
+        }
+        if (swap) return launch_cfg<IDV_PW, 4, 1, 2, 1, 2, 32, true, false>(a, st);
+        return launch_cfg<IDV_PW, 4, 1, 2, 1, 2, 32, false, false>(a, st);
+    }
     if (pwcfg != 7 && a.Mtiles % 8 == 0) {
         if (swap) return launch_cfg<IDV_PW, 4, 1, 2, 1, 2, 8, true, false>(a, st);
         return launch_cfg<IDV_PW, 4, 1, 2, 1, 2, 8, false, false>(a, st);

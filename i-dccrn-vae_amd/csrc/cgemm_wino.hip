@@ -457,7 +457,14 @@ int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
 // ring half a chunk deep (7 fragments per unit).
 template <int WM, int WN, int CIK, bool STATS>
 int launch_wino_s(const WinoArgs& a, int transposed, hipStream_t st) {
-    if (!transposed) return launch_wino_ph<2, WM, WN, CIK, STATS, 1, (CIK * 3) / 2>(a, st);
+    if (!transposed) {
+        // two channels per chunk: the conv form at TWO workgroups per CU (one staging item per thread, ring of three units: 253
+        // registers, accumulators in VGPRs)
+        if constexpr (CIK == 2) return launch_wino_ph<2, WM, WN, 2, STATS, 2, 3>(a, st);
+        else return launch_wino_ph<2, WM, WN, CIK, STATS, 1, (CIK * 3) / 2>(a, st);
+    }
+    if constexpr (CIK == 2) return IDV_EINVAL;                 // (the transposed form picks its own chunk sizes below)
+    else {
     static const int ph1 = [] { const char* e = getenv("IDV_WINO_PH1"); return e ? atoi(e) : 1; }();
     // the even-row phase runs at two workgroups per CU too where it fits 256 registers (accumulators in VGPRs): the four-co-tile
     // form with four channels per chunk and a weight ring of four units (249 registers): dec0 11.09 -> 10.49 ms, dec1 10.13 -> 9.62,
@@ -471,6 +478,7 @@ int launch_wino_s(const WinoArgs& a, int transposed, hipStream_t st) {
     } else if (int rc = launch_wino_ph<0, WM, WN, CIK, STATS>(a, st)) return rc;
     if (ph1 == 0) return launch_wino_ph<1, WM, WN, CIK, STATS>(a, st);
     return launch_wino_ph<1, WM, WN, CIK, STATS, 2, (CIK * 3) % 8 == 0 ? 8 : 6>(a, st);
+    }
 }
 template <int WM, int WN, int CIK>
 int launch_wino(const WinoArgs& a, int transposed, hipStream_t st) {
@@ -485,13 +493,13 @@ const bool USE_WINO_CONV = [] { const char* e = getenv("IDV_WINO_CONV"); return 
 // 1 if the Winograd form serves this layer: what cgemm_gauss serves, where it measured faster (B = 64, tests/tools/
 // wino_layers_probe.py): transposed conv with more than one tile of 32 complex output channels (one co tile x four column groups was
 // 3 % SLOWER than cgemm_gauss's two-workgroup form on dec4, 128 -> 32: the staging transform is then amortised over one co tile
-// only) and at least two input rows; conv with >= 128 input AND output channels (enc3 5.69 -> 5.38 ms, enc4 6.08 -> 5.86, enc5
-// 6.78 -> 6.69; enc2 64 -> 128 ties, enc1 32 -> 64 loses: cgemm_gauss runs those at two workgroups per CU) and >= 2 output rows.
+// only) and at least two input rows; conv with >= 128 output channels (four co tiles) and >= 64 input channels (enc2 5.62 -> 4.90
+// ms, enc3 5.66 -> 5.04, enc4 6.03 -> 5.44, enc5 6.73 -> 6.30 at two workgroups per CU; enc1, 32 -> 64, loses) and >= 2 output rows.
 extern "C" int idv_cconv_wino_supported(int transposed, int C0, int C1, int Cout, int Fin) {
     static const int min_cout = [] { const char* e = getenv("IDV_WINO_MIN_COUT"); return e ? atoi(e) : 33; }();
-    static const int conv_min = [] { const char* e = getenv("IDV_WINO_CONV_MINC"); return e ? atoi(e) : 128; }();
+    static const int conv_min = [] { const char* e = getenv("IDV_WINO_CONV_MINC"); return e ? atoi(e) : 64; }();
     if (!USE_WINO || (!transposed && !USE_WINO_CONV) || Cout < min_cout) return 0;
-    if (transposed ? Fin < 2 : ((Fin - 1) / 2 + 1 < 2 || Cout < conv_min || C0 + C1 < conv_min)) return 0;
+    if (transposed ? Fin < 2 : ((Fin - 1) / 2 + 1 < 2 || Cout < 128 || C0 + C1 < conv_min)) return 0;
     return idv_cconv_gauss_supported(C0, C1, Cout);
 }
 
@@ -506,7 +514,9 @@ extern "C" long long idv_cconv_wino_wfrag_floats(int transposed, int Cout, int c
 // 10.94, dec2 11.46 -> 10.09 (418); dec3 11.75 -> 10.59 (228)
 extern "C" int idv_cconv_wino_config(int transposed, int Cin, int Cout) {
     (void)Cin;
-    if (!transposed) return Cout >= 128 ? 418 : 228;
+    // conv: four co tiles x one column group at two workgroups per CU (enc3 5.35 -> 5.04 ms, enc4 5.66 -> 5.44 against the
+    // one-workgroup form with eight channels per chunk)
+    if (!transposed) return Cout >= 128 ? 412 : 228;
     return Cout >= 128 ? 418 : (Cout > 32 ? 228 : 144);
 }
 
@@ -559,8 +569,10 @@ extern "C" int idv_cconv2d_wino_fwd(const float* x0, int C0, const float* x1, in
     static const int xccfg = [] { const char* e = getenv("IDV_WINO_CCFG"); return e ? atoi(e) : 0; }();
     int cfg = transposed ? xcfg : xccfg;
     if (!cfg) cfg = idv_cconv_wino_config(transposed, C0 + C1, Cout);
-    if (C1 > 0 && C0 % (cfg % 10)) cfg = cfg / 10 * 10 + 4;          // a K chunk must not straddle the two sources (C0 % 4 == 0 holds)
+    if (C1 > 0 && C0 % (cfg % 10)) cfg = cfg / 10 * 10 + 4;
+    if (transposed && cfg % 10 == 2) return IDV_EINVAL;          // a K chunk must not straddle the two sources (C0 % 4 == 0 holds)
     switch (cfg) {
+        case 412: rc = launch_wino<4, 1, 2>(a, transposed, st); break;
         case 414: rc = launch_wino<4, 1, 4>(a, transposed, st); break;
         case 418: rc = launch_wino<4, 1, 8>(a, transposed, st); break;
         case 224: rc = launch_wino<2, 2, 4>(a, transposed, st); break;

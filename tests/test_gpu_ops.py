@@ -121,7 +121,7 @@ def test_cconv_gauss(ops, causal, transposed, cin, cout, F, T, B, skip_c, skip_d
     (True, True, 256, 64, 17, 70, 2, 0, True, 0.25),      # a real layer width (dec3's channels)
     (False, True, 32, 64, 129, 70, 2, 0, False, None),    # conv: two co tiles x two column groups, odd output row count (65)
     (False, True, 8, 40, 65, 33, 2, 0, True, 0.2),        # conv: ragged second co tile, fold + PReLU
-    (False, True, 16, 128, 17, 40, 3, 0, False, None),    # conv: four co tiles x one column group
+    (False, True, 72, 128, 17, 40, 3, 0, False, None),    # conv: four co tiles x one column group, 72 input channels (served from 64)
     (False, True, 3, 36, 9, 21, 2, 0, False, 0.1),        # conv: odd channel count, 5 output rows (three tiles, the last half empty)
     (False, False, 4, 40, 17, 9, 2, 0, False, None),      # conv: non-causal taps (x[t], x[t+1])
     (False, True, 2, 48, 5, 700, 1, 0, False, None),      # conv: many column tiles, 3 output rows
