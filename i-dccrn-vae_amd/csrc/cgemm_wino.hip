@@ -493,13 +493,14 @@ const bool USE_WINO_CONV = [] { const char* e = getenv("IDV_WINO_CONV"); return 
 // 1 if the Winograd form serves this layer: what cgemm_gauss serves, where it measured faster (B = 64, tests/tools/
 // wino_layers_probe.py): transposed conv with more than one tile of 32 complex output channels (one co tile x four column groups was
 // 3 % SLOWER than cgemm_gauss's two-workgroup form on dec4, 128 -> 32: the staging transform is then amortised over one co tile
-// only) and at least two input rows; conv with >= 128 output channels (four co tiles) and >= 64 input channels (enc2 5.62 -> 4.90
-// ms, enc3 5.66 -> 5.04, enc4 6.03 -> 5.44, enc5 6.73 -> 6.30 at two workgroups per CU; enc1, 32 -> 64, loses) and >= 2 output rows.
+// only) and at least two input rows; conv with >= 64 output and >= 32 input channels (at two workgroups per CU: enc1 2.99 -> 2.61
+// ms on the 2 x 2 form, enc2 5.62 -> 4.90, enc3 5.66 -> 5.04, enc4 6.03 -> 5.44, enc5 6.73 -> 6.30 on four co tiles) and >= 2 output rows.
 extern "C" int idv_cconv_wino_supported(int transposed, int C0, int C1, int Cout, int Fin) {
     static const int min_cout = [] { const char* e = getenv("IDV_WINO_MIN_COUT"); return e ? atoi(e) : 33; }();
-    static const int conv_min = [] { const char* e = getenv("IDV_WINO_CONV_MINC"); return e ? atoi(e) : 64; }();
+    static const int conv_min = [] { const char* e = getenv("IDV_WINO_CONV_MINC"); return e ? atoi(e) : 32; }();
     if (!USE_WINO || (!transposed && !USE_WINO_CONV) || Cout < min_cout) return 0;
-    if (transposed ? Fin < 2 : ((Fin - 1) / 2 + 1 < 2 || Cout < 128 || C0 + C1 < conv_min)) return 0;
+    static const int conv_mincout = [] { const char* e = getenv("IDV_WINO_CONV_MINCOUT"); return e ? atoi(e) : 64; }();
+    if (transposed ? Fin < 2 : ((Fin - 1) / 2 + 1 < 2 || Cout < conv_mincout || C0 + C1 < conv_min)) return 0;
     return idv_cconv_gauss_supported(C0, C1, Cout);
 }
 
@@ -516,7 +517,7 @@ extern "C" int idv_cconv_wino_config(int transposed, int Cin, int Cout) {
     (void)Cin;
     // conv: four co tiles x one column group at two workgroups per CU (enc3 5.35 -> 5.04 ms, enc4 5.66 -> 5.44 against the
     // one-workgroup form with eight channels per chunk)
-    if (!transposed) return Cout >= 128 ? 412 : 228;
+    if (!transposed) return Cout >= 128 ? 412 : 222;
     return Cout >= 128 ? 418 : (Cout > 32 ? 228 : 144);
 }
 
@@ -575,6 +576,7 @@ extern "C" int idv_cconv2d_wino_fwd(const float* x0, int C0, const float* x1, in
         case 412: rc = launch_wino<4, 1, 2>(a, transposed, st); break;
         case 414: rc = launch_wino<4, 1, 4>(a, transposed, st); break;
         case 418: rc = launch_wino<4, 1, 8>(a, transposed, st); break;
+        case 222: rc = launch_wino<2, 2, 2>(a, transposed, st); break;
         case 224: rc = launch_wino<2, 2, 4>(a, transposed, st); break;
         case 228: rc = launch_wino<2, 2, 8>(a, transposed, st); break;
         case 144: rc = launch_wino<1, 4, 4>(a, transposed, st); break;
