@@ -57,6 +57,7 @@ struct WinoArgs {
     const float* add;     // optional addend (see cgemm_gauss.hip)
     int add_div, add_Jp;
     int jtiles, ftiles, mblocks;
+    int xcd_split;        // block order: co-tile blocks on different XCDs (see the kernel)
 };
 
 constexpr int WCIK = 8;          // pack granularity in complex input channels (= cgemm_gauss's: shared `supported` rule); the kernel's K
@@ -114,12 +115,23 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void cconv_wino_kernel(const Wino
     // on consecutive slots of it
     const int MB = a.mblocks, FTn = a.ftiles;
     const int bid = blockIdx.x;
-    const int per = 8 * MB * FTn;
-    const int sg = bid / per, rem = bid - sg * per;
-    const int v = rem >> 3;
-    const int jt = sg * 8 + (rem & 7);
-    const int ft = v / MB;
-    const int mblk = v - (v / MB) * MB;
+    int jt, ft, mblk;
+    if (a.xcd_split) {
+        // the MB co-tile blocks go to DIFFERENT XCDs (block ids equal mod 8 share an XCD): an XCD then streams 1 / MB of the
+        // layer's weights, which its L2 holds, instead of all of them (MB = 2, 4 or 8; a column block is read by MB XCDs)
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int G = 8 / MB;                           // XCD groups per co-tile block
+        mblk = xcd % MB;
+        jt = (slot / FTn) * G + xcd / MB;
+        ft = slot - (slot / FTn) * FTn;
+    } else {
+        const int per = 8 * MB * FTn;
+        const int sg = bid / per, rem = bid - sg * per;
+        const int v = rem >> 3;
+        jt = sg * 8 + (rem & 7);
+        ft = v / MB;
+        mblk = v - (v / MB) * MB;
+    }
     if (jt >= a.jtiles) return;
     const int j0 = jt * JT;
     const int ct = mblk * WM + wm;
@@ -440,7 +452,15 @@ int launch_wino_ph(const WinoArgs& a, hipStream_t st) {
     b.ftiles = PH == 2 ? (a.Fout + 1) / 2 : (PH == 1 ? a.Fin / 2 : (a.Fin + 1) / 2);
     b.mblocks = (a.cotiles + WM - 1) / WM;
     if (b.ftiles == 0) return IDV_OK;
-    const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
+    // co-tile blocks on different XCDs where a layer has 2 / 4 / 8 of them: dec0 (8 co tiles = 2 blocks) 10.75 -> 10.45 ms, no
+    // change elsewhere (the L2-miss traffic is not what bounds these kernels); IDV_WINO_XCD_SPLIT=0: all blocks of a tile on one XCD
+    static const int xsplit = [] { const char* e = getenv("IDV_WINO_XCD_SPLIT"); return e ? atoi(e) : 1; }();
+    b.xcd_split = (xsplit && (b.mblocks == 2 || b.mblocks == 4 || b.mblocks == 8)) ? 1 : 0;
+    long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.mblocks;
+    if (b.xcd_split) {
+        const int G = 8 / b.mblocks;
+        nblk = (long long)((b.jtiles + G - 1) / G) * b.ftiles * 8;
+    }
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
     auto k = cconv_wino_kernel<PH, WM, WN, CIK, NBUF, STATS, OCC, RD>;
     // OCC 1: more than half a CU's LDS, i.e. one workgroup per CU whatever the register count says

@@ -1,8 +1,8 @@
 #!/bin/bash
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r04v
-python -m pytest tests -q -m gpu -x > gpurun_out/r04v/full_suite.log 2>&1; echo "suite rc=$?"; tail -3 gpurun_out/r04v/full_suite.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/r04v/bench_default.json 2> gpurun_out/r04v/bench_default.err; python3 -c "
-import json;d=json.load(open('gpurun_out/r04v/bench_default.json'));print(d['value'],d['ms_per_step'],d['roofline']['frac'],d['roofline'].get('frac_executed'),d['alt']['value'],d['two_stream']['value'],d['two_stream']['bit_exact'],d['cpu_baseline']['value'])"
-for w in dccrn_cl_train nsvae_train twophase_train cvae_train; do python bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/r04v/bench_$w.json 2>/dev/null; python3 -c "
-import json,sys;d=json.load(open('gpurun_out/r04v/bench_$w.json'));print('$w',d['value'],d['ms_per_step'])"; done
+mkdir -p gpurun_out/r04w
+python tests/tools/wino_layers_probe.py 64 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r04w/wino_cfgs.log
+IDV_WINO_XCD_SPLIT=1 python tests/tools/wino_layers_probe.py 64 2>&1 | grep -v amdgpu.ids | sed 's/^/[xsplit 418] /' | tee -a gpurun_out/r04w/wino_cfgs.log
+IDV_WINO_XCD_SPLIT=1 IDV_WINO_CFG=228 python tests/tools/wino_layers_probe.py 64 2>&1 | grep -v amdgpu.ids | sed 's/^/[xsplit 228] /' | tee -a gpurun_out/r04w/wino_cfgs.log
+IDV_WINO_XCD_SPLIT=0 IDV_WINO_CFG=228 python tests/tools/wino_layers_probe.py 64 2>&1 | grep -v amdgpu.ids | sed 's/^/[nosplit 228] /' | tee -a gpurun_out/r04w/wino_cfgs.log
+IDV_WINO_XCD_SPLIT=1 timeout -k 10 300 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "wino" 2>&1 | tail -2
