@@ -495,6 +495,8 @@ int launch_wino_s(const WinoArgs& a, int transposed, hipStream_t st) {
         if (int rc = launch_wino_ph<0, 4, 1, 4, STATS, 2, 4>(a, st)) return rc;
     } else if (ph0 == 2 && WM == 2 && WN == 2) {
         if (int rc = launch_wino_ph<0, 2, 2, 2, STATS, 2, 3>(a, st)) return rc;
+    } else if (ph0 == 2 && WM == 1 && WN == 4) {          // one co tile x four column groups: two channels per chunk (5 registers spilled)
+        if (int rc = launch_wino_ph<0, 1, 4, 2, STATS, 2, 3>(a, st)) return rc;
     } else if (int rc = launch_wino_ph<0, WM, WN, CIK, STATS>(a, st)) return rc;
     if (ph1 == 0) return launch_wino_ph<1, WM, WN, CIK, STATS>(a, st);
     return launch_wino_ph<1, WM, WN, CIK, STATS, 2, (CIK * 3) % 8 == 0 ? 8 : 6>(a, st);
