@@ -1,3 +1,4 @@
+"""fp32 GEMM throughput of the vendor library (torch.matmul -> hipBLASLt / rocBLAS) at the LSTM input-projection shapes: the yardstick\nfor cgemm_kernel<IDV_PW>.  python tests/tools/gemm_library_probe.py   (GPU box)"""
 import torch, time
 dev="cuda"
 def bench(M,K,N,ta=False,tb=False):
