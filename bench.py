@@ -145,6 +145,7 @@ def build_workload(name, B, device, rank):
         return step, B, {"workload": what, "batch_per_gpu": B, "num_samples": ns}
     par = importlib.import_module("i-dccrn-vae_amd.parallel")
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist_on = world > 1 or (FORCE_DIST and "WORLD_SIZE" in os.environ)     # rehearsal: the N-rank code path with one rank
 
     def train_step(models, fwd_loss):
         """zero_grad -> forward + loss -> backward -> [gradient all-reduce] -> Adam.step (lr 1e-3, weight_decay 1e-3:
@@ -154,8 +155,8 @@ def build_workload(name, B, device, rank):
         hip_adam = os.environ.get("IDV_TORCH_ADAM", "0") != "1"
         optim = importlib.import_module("i-dccrn-vae_amd.optim")
         opt = (optim.Adam if hip_adam else torch.optim.Adam)(params, lr=1e-3, weight_decay=1e-3)
-        red = par.GradAllReduce(params) if world > 1 else None
-        if world > 1:
+        red = par.GradAllReduce(params) if dist_on else None
+        if dist_on:
             par.enable_sync_bn()
 
         def step():
@@ -360,6 +361,10 @@ def self_launch(n_gpus: int) -> int:
 
 
 TRAIN_WORKLOADS = ("dccrn_cl_train", "cvae_train", "nsvae_train", "twophase_train")
+# Rehearsal of the N-rank code path on ONE GPU: under `python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1` a
+# process group of one rank is created over RCCL, the barriers, the timing all-reduce and (train workloads, with IDV_DP_FORCE=1)
+# the Sync-CBN moment and gradient-bucket all-reduces are issued; the numbers are those of one GPU.
+FORCE_DIST = os.environ.get("IDV_BENCH_FORCE_DIST", "0") == "1"
 
 
 def kernel_name(cfg_id):
@@ -572,7 +577,8 @@ def main():
     local = local % max(ndev, 1)                 # rehearsal of N ranks on fewer GPUs (IDV_BENCH_BACKEND=gloo) shares devices
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    dist_on = world > 1 or (FORCE_DIST and "WORLD_SIZE" in os.environ)
+    if dist_on:
         # RCCL before any other GPU work of this process
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -594,7 +600,7 @@ def main():
         log(f"warmup step {w} done")
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     elapsed, launches, last = timed(step, args.steps, ops, barrier)
@@ -603,8 +609,8 @@ def main():
     n_streams = ops.stream_split(args.batch) if args.workload == "dccrn_cl" else 1
 
     dt = importlib.import_module("i-dccrn-vae_amd.utils.dist_timing")
-    red_dev = device if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
-    value, elapsed_max = dt.job_throughput(elapsed, float(utt_per_step * args.steps), red_dev)
+    red_dev = device if (not dist_on or dist.get_backend() == "nccl") else torch.device("cpu")
+    value, elapsed_max = dt.job_throughput(elapsed, float(utt_per_step * args.steps), red_dev, force=dist_on)
     roofline = roofline_of(launches, args.steps, elapsed / args.steps, args.precision, args.batch, args.workload)
     if roofline is not None and n_streams > 1:
         roofline["note"] = (f"timed region ran {n_streams} sub-batch streams (IDV_STREAM_SPLIT): event intervals include CU "
@@ -641,9 +647,9 @@ def main():
     if rank == 0:
         out = {
             "metric": METRIC, "value": round(value, 3), "unit": "utterances/sec",
-            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist_on else 1),
             "backend": ((dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else " (rehearsal, no RCCL)"))
-                        if world > 1 else "none (single process)"),
+                        if dist_on else "none (single process)"),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
@@ -666,7 +672,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -4,11 +4,12 @@ exchange nothing but this one timing reduction (RCCL on the GPU box, gloo in the
 from __future__ import annotations
 
 
-def job_throughput(elapsed_s: float, units: float, device=None):
-    """-> (units_per_second over all ranks, max elapsed).  Works with or without an initialised process group."""
+def job_throughput(elapsed_s: float, units: float, device=None, force: bool = False):
+    """-> (units_per_second over all ranks, max elapsed).  Works with or without an initialised process group; force: issue the
+    two reductions also in a group of ONE rank (rehearsal of the N-rank path on one GPU)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return units / elapsed_s, elapsed_s
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     u = torch.tensor([units], dtype=torch.float64, device=device)

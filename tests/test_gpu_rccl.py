@@ -152,3 +152,28 @@ def test_rccl_one_rank_executes_the_data_parallel_step():
         e = float(np.linalg.norm(va.astype("float64") - vb)) / (float(np.linalg.norm(vb.astype("float64"))) + 1e-30)
         assert e < 1e-4, (k, e)                          # (the first Adam step is sign-like: an element with |g| ~ 1e-8 may differ)
     print(f"rccl one-rank step: worst gradient deviation {worst:.2e}, gradients bitwise equal: {bit}")
+
+
+def test_bench_distributed_path_with_one_rccl_rank():
+    """bench.py exactly as the driver launches an N-rank run -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` -- with N = 1 and IDV_BENCH_FORCE_DIST=1 / IDV_DP_FORCE=1: the
+    rank creates the RCCL process group before any other GPU work, runs a data-parallel train workload (Sync-CBN all-reduces,
+    gradient bucket through RCCL, Adam from the bucket), the barriers and the timing all-reduce, and prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IDV_BENCH_FORCE_DIST="1", IDV_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "dccrn_cl_train",
+           "--batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["rccl_ranks"] == 1 and d["backend"].startswith("nccl") and d["n_gpus"] == 1
+    assert d["value"] > 0 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert "data-parallel" in d["config"]["parallelism"]
