@@ -37,6 +37,7 @@ def smoke():
     est, pred = model(noisy.to("cuda:0"), train=False)
     loss = nl.ete_train_se_loss([0.0, 0.0, 1.0]).final_ete_loss(pred, model.stft(clean.to("cuda:0")), clean.to("cuda:0"), est)
     torch.cuda.synchronize()
+    ops.coop_check(sync=False)
     o_est, o_pred, _ = O.dccrn_forward(noisy, sd, np_, True, n_fft, hop, win, skip, "mask", False)
     o_loss = O.multiple_recon_loss(o_pred, O.stft(clean, n_fft, hop, win), clean, o_est, [0.0, 0.0, 1.0])
     rel = float((est.cpu().double() - o_est.double()).norm() / o_est.double().norm())

@@ -112,8 +112,9 @@ def call(name: str, *args):
     rc = fn(*[a.value if isinstance(a, (_I, _L, _F, _D)) else a for a in args])
     if rc != 0:
         what = {-1: "invalid argument", -2: "launch failure",
-                -3: "an earlier cooperative recurrence timed out (a sibling workgroup never became resident); its outputs "
-                    "are NaN-poisoned, this call was not launched"}.get(rc, "?")
+                -3: "a cooperative recurrence of this device timed out earlier (a sibling workgroup never became resident); its "
+                    "outputs are NaN-poisoned, this call was not launched and none will be until ops.coop_clear() / "
+                    "idv_coop_last_status(1) acknowledges the fault"}.get(rc, "?")
         raise IdvError(f"{name} failed with status {rc} ({what})")
 
 

@@ -8,7 +8,8 @@
 //   * the launch chain: cooperative launches of different streams of one device are ordered through an event, because two
 //     half-resident launches would wait for each other until the spin bound poisons both;
 //   * a sticky status word in host-mapped memory: a kernel whose bounded spin ran out (outputs poisoned with NaN) also
-//     stores 1 there (system scope), and the NEXT cooperative entry -- or idv_coop_last_status() -- reports IDV_ECOOP.
+//     stores 1 there (system scope); from then on idv_coop_last_status() and EVERY cooperative entry of the device report
+//     IDV_ECOOP until idv_coop_last_status(1) acknowledges it (a sticky device error: no caller can consume it by accident).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,8 +17,8 @@
 
 // workgroups a cooperative launch may use on the current device (no device visible: the MI355X figure, 240)
 extern "C" int idv_coop_max_workgroups(void);
-// take the chain lock and make `st` wait for the previous cooperative launch of this device.  Returns IDV_ECOOP (lock NOT held)
-// if an earlier cooperative launch timed out and nobody has collected that status yet.
+// take the chain lock and make `st` wait for the previous cooperative launch of this device.  Returns IDV_ECOOP (lock NOT held,
+// status NOT cleared) while an earlier cooperative launch's time-out has not been acknowledged with idv_coop_last_status(1).
 int idv_coop_chain_begin(hipStream_t st);
 // record the launch + release the lock; must follow every successful idv_coop_chain_begin, on every path
 int idv_coop_chain_end(hipStream_t st);

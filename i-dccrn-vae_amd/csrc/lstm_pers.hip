@@ -392,7 +392,7 @@ unsigned* idv_coop_status_word() {
 }
 
 // IDV_ECOOP if a cooperative kernel of the current device has timed out since the status was last cleared (its outputs are
-// NaN-poisoned); clear != 0 resets it.  The word is written by the device when the kernel aborts, so a launch that is
+// NaN-poisoned); clear != 0 acknowledges and resets it -- until then every cooperative entry of the device refuses with IDV_ECOOP.  The word is written by the device when the kernel aborts, so a launch that is
 // still queued is not covered: synchronise the stream first for a definite answer.
 extern "C" int idv_coop_last_status(int clear) {
     const int dev = cur_dev();
@@ -410,10 +410,9 @@ int idv_coop_chain_begin(hipStream_t st) {
     if (dev < 0) return IDV_ELAUNCH;
     g_pers_mu.lock();
     volatile unsigned* w = g_status_host[dev];
-    if (w && *w) {                       // an earlier cooperative launch timed out: report it once, then carry on
-        *w = 0u;
-        g_pers_mu.unlock();
-        return IDV_ECOOP;
+    if (w && *w) {                       // an earlier cooperative launch timed out and nobody has acknowledged it: refuse, like a
+        g_pers_mu.unlock();              // sticky device error, until idv_coop_last_status(1) -- the status is NOT consumed here,
+        return IDV_ECOOP;                // so an unrelated caller cannot swallow it
     }
     if (g_pers_done[dev] && g_pers_stream[dev] != st && hipStreamWaitEvent(st, g_pers_done[dev], 0) != hipSuccess) {
         g_pers_mu.unlock();

@@ -35,13 +35,21 @@ def mean_over_samples(recon: torch.Tensor, num_samples: int) -> torch.Tensor:
 
 
 @torch.no_grad()
-def enhance_supervised(model, noisy: torch.Tensor) -> torch.Tensor:
-    """DCCRN / DCCRN-CL: [B, L] -> enhanced [B, hop*(T-1)]."""
-    return model(noisy, train=False)[0]
+def enhance_supervised(model, noisy: torch.Tensor, check: bool = True) -> torch.Tensor:
+    """DCCRN / DCCRN-CL: [B, L] -> enhanced [B, hop*(T-1)].  ``check`` (all three entry points): synchronise and raise
+    ``ops.CoopTimeout`` here, at the operation that owns it, if a cooperative LSTM recurrence of this forward timed out
+    (its outputs would be NaN); ``check=False`` keeps the call asynchronous (call ``ops.coop_check()`` yourself)."""
+    return _checked(model(noisy, train=False)[0], check)
+
+
+def _checked(out: torch.Tensor, check: bool) -> torch.Tensor:
+    if check:
+        ops.coop_check()
+    return out
 
 
 @torch.no_grad()
-def enhance_vae(noisy_encoder, decoder, noisy: torch.Tensor, eps=None, latent: str = "speech") -> torch.Tensor:
+def enhance_vae(noisy_encoder, decoder, noisy: torch.Tensor, eps=None, latent: str = "speech", check: bool = True) -> torch.Tensor:
     """I-DCCRN-VAE (phase 2, latent_to_use 1): [B, L] -> mean of the num_samples decoded waveforms, [B, hop*(T-1)].
     ``eps``: optional injected Gaussian draws (see the encoder's forward)."""
     r = noisy_encoder(noisy, train=False, eps=eps)
@@ -50,7 +58,7 @@ def enhance_vae(noisy_encoder, decoder, noisy: torch.Tensor, eps=None, latent: s
         raise ValueError("this encoder has no noise latent (latent_num == 1)")
     skiper, C, F, stft_x = r[8], r[9], r[10], r[11]
     recon, _ = decoder(stft_x, z, skiper, C, F, train=False, pad="sig")
-    return mean_over_samples(recon, noisy_encoder.num_samples)
+    return _checked(mean_over_samples(recon, noisy_encoder.num_samples), check)
 
 
 OUTTYPES = {"real_imag_mask": 0, "complex_mask": 1, "phase_mask": 2}
@@ -84,7 +92,7 @@ def outtype_estimate(predict_noise: torch.Tensor, predict_speech: torch.Tensor, 
 
 @torch.no_grad()
 def enhance_vae_two_latents(noisy_encoder, speech_decoder, noise_decoder, noisy: torch.Tensor, outtype: str = "clean_direct",
-                            phase: int = 2, eps=None) -> torch.Tensor:
+                            phase: int = 2, eps=None, check: bool = True) -> torch.Tensor:
     """latent_to_use == 2 (test_se_cvaefinetune.py:261-305): the noisy encoder's speech latent through the speech decoder and
     its noise latent through the noise decoder (phase 1: the pre-trained decoders, zero skips, :263-264; phase 2: the
     fine-tuned decoders with the noisy skips, ``pad='sig'``, :295-296), then the ``outtype`` estimator -> enhanced [B, L]."""
@@ -96,12 +104,12 @@ def enhance_vae_two_latents(noisy_encoder, speech_decoder, noise_decoder, noisy:
     rec_s, pred_s = speech_decoder(stft_x, z_s, skiper, C, F, train=False, **kw)
     ns = noisy_encoder.num_samples
     if outtype == "clean_direct":
-        return mean_over_samples(rec_s, ns)
+        return _checked(mean_over_samples(rec_s, ns), check)
     _, pred_n = noise_decoder(stft_x, z_n, skiper, C, F, train=False, **kw)
     spec, _ = outtype_estimate(pred_n, pred_s, stft_x, outtype, ns)
     from .model.pvae_module import dft_plan
     st = noisy_encoder.stft
-    return ops.istft(spec, dft_plan(st.n_fft, st.win_length, st.hop_length, spec.T, spec.buf.device))
+    return _checked(ops.istft(spec, dft_plan(st.n_fft, st.win_length, st.hop_length, spec.T, spec.buf.device)), check)
 
 
 def compute_sisdr(x_est: torch.Tensor, x_ref: torch.Tensor) -> torch.Tensor:

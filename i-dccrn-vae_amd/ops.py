@@ -450,6 +450,29 @@ def hand_over(obj, stream):
             hand_over(o, stream)
 
 
+class CoopTimeout(RuntimeError):
+    """A cooperative (spin-synchronised) recurrence ran into its spin bound: its outputs are NaN-poisoned."""
+
+
+def coop_check(sync: bool = True, clear: bool = True) -> None:
+    """Report a cooperative recurrence's time-out AT THE OPERATION THAT OWNS IT: call after the forward / step whose result is
+    about to be used (inference.py's entry points, bench.py's timed region and smoke() do).  `sync` synchronises the current
+    stream first -- the status word is written by the device when the kernel aborts.  Raises CoopTimeout and, with `clear`,
+    acknowledges the fault so that the next cooperative launch runs again; without it every cooperative entry keeps refusing
+    with status -3 (sticky, like a device error), csrc/coop.hpp."""
+    if sync:
+        torch.cuda.current_stream().synchronize()
+    if L.lib().idv_coop_last_status(1 if clear else 0) != 0:
+        raise CoopTimeout("a cooperative LSTM recurrence timed out on this device (a sibling workgroup never became resident, e.g. "
+                          "a CU-masked or shared GPU): results computed since the last check are NaN-poisoned"
+                          + ("" if clear else "; cooperative launches are refused until ops.coop_clear()"))
+
+
+def coop_clear() -> bool:
+    """Acknowledge a cooperative time-out without raising; True if there was one."""
+    return L.lib().idv_coop_last_status(1) != 0
+
+
 # Train-mode moment sums: the conv epilogues spread their atomic adds over this many replicas of the [Cout][5] sums
 # (idv_cconv2d_fwd / idv_cconv2d_gauss_fwd stats_work); IDV_STATS_REP=1 keeps one set
 STATS_REP = int(os.environ.get("IDV_STATS_REP", "32"))

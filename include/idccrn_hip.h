@@ -10,7 +10,7 @@
  *     CU count, an event that orders cooperative launches of different streams, and a 256-byte host-mapped status word
  *     (see idv_coop_last_status);
  *   - return value: 0 ok, -1 invalid argument, -2 launch failure, -3 (IDV_ECOOP) an EARLIER cooperative recurrence ran into
- *     its spin bound (its outputs are NaN-poisoned); nothing throws;
+ *     its spin bound (its outputs are NaN-poisoned) and that has not been acknowledged yet (idv_coop_last_status); nothing throws;
  *   - activations use the planar-J layout  act[ri][C][F][Jp]  (fp32):
  *       column j = b*Tp + tp, Tp = T+1, tp = t+1, tp==0 and tp>t_valid are zero guard columns,
  *       Jp >= B*Tp is the row stride; buffers need IDV_SLACK floats of slack in front and behind.
@@ -30,8 +30,10 @@ int idv_abi_version(void);
 
 /* Sticky status of the cooperative recurrences on the current device: -3 if one of them has run into its spin bound (a sibling
  * workgroup never became resident, e.g. on a CU-masked or shared GPU; its outputs were poisoned with NaN) since the status was
- * last cleared, else 0.  clear != 0 resets it.  The next cooperative entry reports (and clears) the same condition by returning
- * -3 without launching.  The word is written by the device: synchronise the stream first for a definite answer. */
+ * last cleared, else 0.  clear != 0 acknowledges and resets it.  The status is sticky like a device error: until it is
+ * acknowledged EVERY cooperative entry of the device returns -3 without launching, so no unrelated caller can consume it.  The
+ * operation that owns the time-out is the one whose stream was synchronised last: check after the synchronise (the Python
+ * side does: ops.coop_check()).  The word is written by the device: synchronise the stream first for a definite answer. */
 int idv_coop_last_status(int clear);
 /* Workgroups a cooperative launch may use on the current device: multiProcessorCount minus 1/16 head room (240 on MI355X). */
 int idv_coop_max_workgroups(void);
