@@ -257,11 +257,11 @@ def pack_cconv_gauss(w_re, w_im, b_re, b_im, fold, cin_used: Optional[int] = Non
         # versa: same memory, the other interpretation, W_i negated (idv_pack_cconv_adjoint does the same)
         call("idv_pack_cconv_gauss", p(w_re), p(w_im), p(None), p(None), p(None), i(cout), i(cin_total), i(cin_used),
              i(1 if transposed else 0), i(1), p(wfrag), p(epi), stream_ptr())
-        return wfrag, epi, 0, _pack_wino(w_re, w_im, cout, cin_total, cin_used, transposed, 1)
+        return (wfrag, epi, 0) + _pack_wino_tw(w_re, w_im, cout, cin_total, cin_used, transposed, 1)
     w_re, w_im = w_re.contiguous(), w_im.contiguous()
     call("idv_pack_cconv_gauss", p(w_re), p(w_im), p(b_re.contiguous()), p(b_im.contiguous()), p(fold),
          i(cout), i(cin_total), i(cin_used), i(1 if transposed else 0), i(0), p(wfrag), p(epi), stream_ptr())
-    return wfrag, epi, (1 if fold is not None else 0), _pack_wino(w_re, w_im, cout, cin_total, cin_used, transposed, 0)
+    return (wfrag, epi, (1 if fold is not None else 0)) + _pack_wino_tw(w_re, w_im, cout, cin_total, cin_used, transposed, 0)
 
 
 # fp32 convs / transposed convs with Winograd-transformed frequency taps on top of the three-product form (csrc/cgemm_wino.hip):
@@ -282,6 +282,27 @@ def _pack_wino(w_re, w_im, cout: int, cin_total: int, cin_used: int, transposed:
     return wf
 
 
+# ... and, for the transposed operators, with the TIME taps in Winograd form too (csrc/cgemm_tw.hip): 3 instead of 4 products per pair
+# of output columns.  Opt-in while it is being measured: IDV_TW=1 (or ops.TW = True before the weights are packed).
+TW = os.environ.get("IDV_TW", "0") == "1"
+TW_CFG = 5000000                 # LAUNCH_LOG id of a launch on the time-Winograd kernels
+
+
+def _pack_wino_tw(w_re, w_im, cout: int, cin_total: int, cin_used: int, transposed: bool, conj: int):
+    """-> (wino fragments | None, time-Winograd fragments | None): the tail of a gauss pack tuple."""
+    wf = _pack_wino(w_re, w_im, cout, cin_total, cin_used, transposed, conj)
+    if wf is None or not (TW and transposed):
+        return wf, None
+    tw = torch.empty(int(_ll_fn("idv_cconv_tw_wfrag_floats")(i(cout), i(cin_used))), dtype=torch.float32, device=w_re.device)
+    call("idv_pack_cconv_tw", p(wf), i(cout), i(cin_used), p(tw), stream_ptr())
+    return wf, tw
+
+
+def _tw_ok(gauss, x: Planar, c1: int, cout: int, skip_jp: Optional[int]) -> bool:
+    return (gauss is not None and TW and len(gauss) > 4 and gauss[4] is not None and x.Jp % 4 == 0
+            and (skip_jp is None or skip_jp == x.Jp) and bool(L.lib().idv_cconv_tw_supported(i(x.C), i(c1), i(cout), i(x.F))))
+
+
 def _wino_ok(gauss, transposed: bool, x: Planar, c1: int, cout: int, skip_jp: Optional[int]) -> bool:
     return (gauss is not None and WINO and len(gauss) > 3 and gauss[3] is not None and x.Jp % 4 == 0
             and (skip_jp is None or skip_jp == x.Jp)
@@ -299,7 +320,7 @@ def pack_cconv_gauss_skip_part(w_re, w_im, c0: int):
     epi = torch.empty(int(lib.idv_cconv_gauss_epi_rows(i(cout))) * 8, dtype=torch.float32, device=wr.device)
     call("idv_pack_cconv_gauss", p(wr), p(wi), p(None), p(None), p(None), i(cout), i(cin), i(cin), i(1), i(0), p(wfrag), p(epi),
          stream_ptr())
-    return wfrag, epi, 0, _pack_wino(wr, wi, cout, cin, cin, True, 0)
+    return (wfrag, epi, 0) + _pack_wino_tw(wr, wi, cout, cin, cin, True, 0)
 
 
 def bf16_supported(transposed: bool, c0: int, c1: int, skip_div: int, cout: int) -> bool:
@@ -531,7 +552,14 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
             ev1.record()
             LAUNCH_LOG.append((cfg, macs, ev0, ev1))
         return out
-    if skip_div == 1 and _wino_ok(gauss, transposed, x, c1, cout, skip.Jp if skip is not None else None):
+    if (transposed and skip_div == 1 and stats is None and addend is None
+            and _tw_ok(gauss, x, c1, cout, skip.Jp if skip is not None else None)):
+        # fp32: Winograd-transformed frequency and time taps (csrc/cgemm_tw.hip)
+        if LAUNCH_LOG is not None:
+            cfg = TW_CFG
+        call("idv_ctconv2d_tw_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1), p(gauss[4]), p(gauss[1]),
+             i(gauss[2]), p(slope), out.ptr(), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+    elif skip_div == 1 and _wino_ok(gauss, transposed, x, c1, cout, skip.Jp if skip is not None else None):
         # fp32: Winograd-transformed frequency taps on top of the three products (csrc/cgemm_wino.hip)
         if LAUNCH_LOG is not None:
             cfg = WINO_CFG + (1000 if transposed else 0) + L.lib().idv_cconv_wino_config(i(1 if transposed else 0), i(x.C + c1), i(cout))
@@ -984,7 +1012,12 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
         if wfrag_bf16 is not None:
             cfg = -(1000000 + L.lib().idv_cconv_bf16_config(i(1 if adj_transposed else 0), i(cout_adj), i(dy.F)))
         ev0.record()
-    if wfrag_bf16 is None and _wino_ok(gauss, adj_transposed, dy, 0, cout_adj, None):
+    if wfrag_bf16 is None and adj_transposed and _tw_ok(gauss, dy, 0, cout_adj, None):
+        if LAUNCH_LOG is not None:
+            cfg = TW_CFG
+        call("idv_ctconv2d_tw_fwd", dy.ptr(), i(dy.C), p(None), i(0), p(gauss[4]), p(gauss[1]), i(0), p(None), out.ptr(),
+             i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), stream_ptr())
+    elif wfrag_bf16 is None and _wino_ok(gauss, adj_transposed, dy, 0, cout_adj, None):
         # the data gradient on the Winograd kernels (csrc/cgemm_wino.hip): adjoint of a conv = a transposed conv and vice versa
         if LAUNCH_LOG is not None:
             cfg = WINO_CFG + (1000 if adj_transposed else 0) + L.lib().idv_cconv_wino_config(i(1 if adj_transposed else 0), i(dy.C), i(cout_adj))

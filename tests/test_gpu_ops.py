@@ -153,6 +153,63 @@ def test_cconv_wino(ops, transposed, causal, cin, cout, F, T, B, skip_c, fold, s
     assert e < 5e-6
 
 
+@pytest.mark.parametrize("causal,cin,cout,F,T,B,skip_c,fold,slope", [
+    (True, 8, 40, 9, 37, 3, 0, True, 0.2),          # two co tiles (ragged second), odd row count: a half tile in the even-row phase
+    (True, 16, 128, 5, 30, 2, 0, False, None),      # four co tiles
+    (True, 8, 40, 6, 30, 2, 8, False, None),        # even row count, skip concat (second source)
+    (True, 6, 36, 2, 9, 2, 0, False, 0.1),          # two input rows (one tile), channel count below the pack granularity
+    (True, 7, 36, 3, 45, 1, 0, True, None),         # odd channel count: ragged last K chunk; odd columns per utterance (Tp = 46)
+    (False, 6, 40, 9, 9, 2, 0, False, None),        # non-causal taps (window column on the right)
+    (True, 32, 64, 33, 645, 2, 32, False, 0.25),    # utterance-length columns, Tp = 646, column tail
+    (True, 256, 64, 17, 70, 2, 0, True, 0.25),      # a real layer width (dec3's channels)
+    (True, 12, 36, 4, 31, 3, 4, False, None),       # B * Tp = 96 odd pairs tail: J not a multiple of 64, second source of 4 channels
+])
+def test_ctconv_time_winograd(ops, causal, cin, cout, F, T, B, skip_c, fold, slope):
+    """The transposed conv with Winograd-transformed frequency AND time taps (csrc/cgemm_tw.hip: F(2,2) over pairs of output
+    columns on top of cgemm_wino) against the oracle's four real convolutions and against cgemm_wino."""
+    keep, keep_tw, keep_log = ops.WINO, ops.TW, ops.LAUNCH_LOG
+    assert ops.L.lib().idv_cconv_tw_supported(cin, skip_c, cout, F)
+    try:
+        ops.WINO = ops.TW = True
+        ops.LAUNCH_LOG = []
+        got = _conv_case(ops, causal, True, cin, cout, F, T, B, seed=61, fold=fold, slope=slope, skip_c=skip_c, gauss=True)
+        assert [c for c, *_ in ops.LAUNCH_LOG if c == ops.TW_CFG], "time-Winograd kernel not launched"
+        ops.TW = False
+        ops.LAUNCH_LOG = []
+        ref = _conv_case(ops, causal, True, cin, cout, F, T, B, seed=61, fold=fold, slope=slope, skip_c=skip_c, gauss=True)
+        assert not [c for c, *_ in ops.LAUNCH_LOG if c == ops.TW_CFG]
+    finally:
+        ops.WINO, ops.TW, ops.LAUNCH_LOG = keep, keep_tw, keep_log
+    e = relerr(got, ref)
+    print(f"time-Winograd vs cgemm_wino: {e:.2e}")
+    assert e < 5e-6
+
+
+def test_ctconv_time_winograd_adjoint(ops):
+    """The data gradient of a conv (= a transposed conv with conjugate-transposed weights, reversed time taps) on the
+    time-Winograd kernels against cgemm_wino."""
+    g = torch.Generator().manual_seed(12)
+    dev = "cuda"
+    keep, keep_tw, keep_log = ops.WINO, ops.TW, ops.LAUNCH_LOG
+    try:
+        for cin, cout, F in ((128, 136, 17), (40, 72, 9), (24, 72, 9)):
+            wr, wi = (torch.randn(cout, cin, 5, 2, generator=g) * 0.1).to(dev), (torch.randn(cout, cin, 5, 2, generator=g) * 0.1).to(dev)
+            Fo = (F - 1) // 2 + 1
+            served = bool(ops.L.lib().idv_cconv_tw_supported(cout, 0, cin, Fo))      # (24 output channels: one co tile, not served)
+            assert served == (cin > 32)
+            dy = ops.Planar.from_tensor5(torch.randn(3, cout, Fo, 37, 2, generator=g).to(dev), 38)
+            d = {}
+            for tw in (False, True):
+                ops.WINO, ops.TW = True, tw
+                ga = ops.pack_cconv_gauss(wr, wi, None, None, None, adjoint_of=(cin, cout, cout, True))
+                ops.LAUNCH_LOG = []
+                d[tw] = ops.cconv_dgrad(dy, None, None, cin, False, True, gauss=ga).tensor5().cpu()
+                assert bool([c for c, *_ in ops.LAUNCH_LOG if c == ops.TW_CFG]) == (tw and served)
+            assert relerr(d[True], d[False]) < 5e-6
+    finally:
+        ops.WINO, ops.TW, ops.LAUNCH_LOG = keep, keep_tw, keep_log
+
+
 def test_cconv_gauss_stats_and_adjoint(ops):
     """Train-mode moment sums of the three-product kernel = those of cgemm_kernel, and its adjoint (data gradient) form =
     the adjoint on cgemm_kernel, for a conv and a transposed conv."""
