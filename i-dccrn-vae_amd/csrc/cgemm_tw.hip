@@ -61,16 +61,19 @@ template <int PH> constexpr int tw_nt() { return tw_nr<PH>() * 9; }            /
 template <int PH> constexpr int tw_ntp() { return PH == 0 ? 36 : 28; }         // tile slots per channel pair in the packed weights
 template <int PH> constexpr int tw_ntw() { return (tw_nt<PH>() + 3) / 4; }     // tiles per wave
 
-template <int PH, int CIK>
+// DBG (timing experiments only, results wrong): 1 = no staging after the prologue, 2 = no weight re-loads, 4 = no epilogue exchange
+// LEFT: the time taps read (x[t-1], x[t]) (tshift = -1: the extra window column is on the left), else (x[t], x[t+1])
+template <int PH, int CIK, bool LEFT, int DBG = 0, int RDW = 2>
 __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
     constexpr int NR = tw_nr<PH>(), NT = tw_nt<PH>(), NTP = tw_ntp<PH>(), NTW = tw_ntw<PH>();
+    constexpr int NRAW = PH == 0 ? 4 : 3, ROW0 = PH == 0 ? 0 : 1;       // raw patch rows d(ROW0) .. : input rows m0 - 1 + ROW0 ..
     constexpr int KS = CIK / 2;                  // MFMA k-steps (channel pairs) per chunk
-    constexpr int BT = NT * 32;                  // floats per channel in a patch buffer: NT transformed rows of 32 column pairs
-    constexpr int NE = CIK * BT;
-    constexpr int NBUF = 3;
-    constexpr int NITEM = CIK * NR * 16;         // staging items per chunk: (channel, frequency product, 2 column pairs)
+    constexpr int RT = NRAW * 9 * 32;            // floats per channel in a patch buffer: per raw row 9 (Gauss, time) planes of 32 pairs
+    constexpr int NE = CIK * RT;
+    constexpr int NBUF = 2;
+    constexpr int NITEM = CIK * NRAW * 16;       // staging items per chunk: (channel, raw row, 2 column pairs)
     constexpr int NLD = (NITEM + 255) / 256;
-    static_assert(NLD == 1, "one staging item per thread");
+    static_assert(KS % RDW == 0 && NLD <= 2, "weight ring slots are compile-time; at most two staging items per thread");
     static_assert(NT * 4 * 64 <= NBUF * NE, "the epilogue exchange fits the patch buffers");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
     if (jt >= a.jtiles) return;
     const int j0 = jt * 64;
     const int m0 = 2 * ft;
-    const int rbase = m0 - 1;
+    const int rbase = m0 - 1 + ROW0;
 
     const int Cin = a.C0 + a.C1;
     const int nchunk = (Cin + CIK - 1) / CIK;
@@ -101,154 +104,251 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
     for (int k = 0; k < NTW; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-    // this wave's tiles t = wave + 4 k.  Two kinds of tile do work nobody reads, branch-free: the 28th slot of the odd-row phase (zero
-    // taps) and, in a half tile, the products r = 3, which only feed the missing second output row.
-    // ---- staging: one item = channel cl, frequency product r, column pairs 2 c8, 2 c8 + 1 (output columns j0 + 4 c8 .. + 3):
-    // window columns w0..w4 = input columns jc + tshift .. jc + 4 + tshift of the two raw rows, real and imaginary
-    f32x4 va_r, va_i, vb_r, vb_i;
-    float ea_r, ea_i, eb_r, eb_i;
-    unsigned offa_v, offa_e, offb_v, offb_e, ldsoff;
-    unsigned okmask = 0;      // bits 0-4: window column valid; bit 5: row A valid; bit 6: row B used and valid; bit 7: item exists
-    float cbv;
-    int item_cl;
-    {
-        const int e = tid;
-        const int c8 = e & 15;
-        const int r = (e >> 4) % NR, cl = e / (16 * NR);
-        item_cl = cl;
-        const int fa = rbase + tw_ra<PH>(r), fb = rbase + tw_rb<PH>(r);
-        cbv = tw_cb<PH>(r);
-        const int jc = j0 + 4 * c8;
-        const int je = a.tshift ? jc - 1 : jc + 4;
-        const bool exists = e < NITEM;
-        const bool oka = exists && fa >= 0 && fa < a.Fin;
-        const bool okb = exists && cbv != 0.f && fb >= 0 && fb < a.Fin;
+    // this wave's tiles.  Even-row phase: wave = frequency product r, tiles t = 9 r + k (k = the 9 (Gauss, time) planes): the LDS
+    // offsets of its operands are one base + compile-time constants.  Odd-row phase: 27 tiles on 4 waves, dealt round-robin
+    // t = wave + 4 k (7 per wave; the 28th slot has zero taps), offsets per tile.  The B operand of tile (r, g, tau) is plane
+    // (g, tau) of raw row ra(r) + cb(r) x the same plane of raw row rb(r) -- the frequency transform at the operand read.  In a half
+    // tile the products r = 3 do work nobody reads (they only feed the missing output row), branch-free.
+    constexpr bool CONTIG = PH == 0;
+    int offA[CONTIG ? 1 : NTW], offB[CONTIG ? 1 : NTW];
+    float cbk[CONTIG ? 1 : NTW];
+    if (CONTIG) {
+        cbk[0] = tw_cb<PH>(wave);
+        offA[0] = (tw_ra<PH>(wave) - ROW0) * 9 * 32;
+        offB[0] = (tw_rb<PH>(wave) - ROW0) * 9 * 32;      // (cb is never 0 in this phase)
+    } else {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int c = jc + i + a.tshift;
-            if (c >= 0 && c < a.J) okmask |= 1u << i;
+        for (int k = 0; k < NTW; ++k) {
+            const int t = wave + 4 * k < NT ? wave + 4 * k : 0;
+            const int r = t / 9, gt = t - r * 9;
+            cbk[k] = tw_cb<PH>(r);
+            offA[k] = ((tw_ra<PH>(r) - ROW0) * 9 + gt) * 32;
+            offB[k] = cbk[k] != 0.f ? ((tw_rb<PH>(r) - ROW0) * 9 + gt) * 32 : offA[k];
         }
-        if (oka) okmask |= 1u << 5;
-        if (okb) okmask |= 1u << 6;
-        if (exists) okmask |= 1u << 7;
+    }
+
+    // ---- staging: one item = channel cl, raw row, column pairs 2 c8, 2 c8 + 1 (output columns j0 + 4 c8 .. + 3): window columns
+    // w0..w4 = input columns jc + tshift .. jc + 4 + tshift, real and imaginary -> the 9 planes (s = r + i | r | i) x (a - b | b | b - d)
+    f32x4 v_r[NLD], v_i[NLD];
+    float e_r[NLD], e_i[NLD];
+    unsigned off_v[NLD], off_e[NLD], ldsoff[NLD];
+    unsigned okmask[NLD];     // bits 0-4: window column valid; bit 5: row valid; bit 7: item exists
+    int item_cl[NLD];
+    bool interior[NLD];       // wave-uniform: every lane's item has its row and all five window columns inside the tensor
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + i * 256;
+        const int c8 = e & 15;
+        const int rl = (e >> 4) % NRAW, cl = e / (16 * NRAW);
+        item_cl[i] = cl;
+        const int f = rbase + rl;
+        const int jc = j0 + 4 * c8;
+        const int je = LEFT ? jc - 1 : jc + 4;
+        const bool exists = e < NITEM;
+        const bool okr = exists && f >= 0 && f < a.Fin;
+        unsigned m = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int c = jc + q + (LEFT ? -1 : 0);
+            if (c >= 0 && c < a.J) m |= 1u << q;
+        }
+        if (okr) m |= 1u << 5;
+        if (exists) m |= 1u << 7;
         // addresses stay inside mapped memory whatever the masks say: vector slot clamped to the row, the extra column to [0, Jp)
         const int jcv = jc + 3 < a.Jp ? jc : 0;
         const int jev = (je >= 0 && je < a.Jp) ? je : 0;
-        offa_v = oka ? (unsigned)((cl * a.Fin + fa) * a.Jp + jcv) : 0u;
-        offa_e = oka ? (unsigned)((cl * a.Fin + fa) * a.Jp + jev) : 0u;
-        offb_v = okb ? (unsigned)((cl * a.Fin + fb) * a.Jp + jcv) : 0u;
-        offb_e = okb ? (unsigned)((cl * a.Fin + fb) * a.Jp + jev) : 0u;
-        if (jc + 3 >= a.Jp) okmask &= ~0x1fu;                 // (a column block past the row pitch: nothing valid)
-        if (!(je >= 0 && je < a.Jp)) okmask &= a.tshift ? ~1u : ~(1u << 4);
-        ldsoff = (unsigned)((cl * NT + r * 9) * 32 + 2 * c8);
+        off_v[i] = okr ? (unsigned)((cl * a.Fin + f) * a.Jp + jcv) : 0u;
+        off_e[i] = okr ? (unsigned)((cl * a.Fin + f) * a.Jp + jev) : 0u;
+        if (jc + 3 >= a.Jp) m &= ~0x1fu;                      // (a column block past the row pitch: nothing valid)
+        if (!(je >= 0 && je < a.Jp)) m &= LEFT ? ~1u : ~(1u << 4);
+        okmask[i] = m;
+        interior[i] = __builtin_amdgcn_ballot_w64((m & 0xbfu) == 0xbfu) == ~0ull;
+        ldsoff[i] = (unsigned)((cl * NRAW + rl) * 9 * 32 + (PH == 0 ? 4 : 2) * c8);
     }
-    auto stage_load = [&](int chunk) {
+    auto stage_load = [&](int chunk, int i) {
         const int ci0 = chunk * CIK;
         const bool from0 = ci0 < a.C0;
         const float* br = from0 ? a.x0 + (size_t)ci0 * a.Fin * a.Jp : a.x1 + (size_t)(ci0 - a.C0) * a.Fin * a.Jp;
         const float* bi = from0 ? br + (size_t)a.C0 * a.Fin * a.Jp : br + (size_t)a.C1 * a.Fin * a.Jp;
         const int cvalid = (from0 ? a.C0 : Cin) - ci0;
-        const bool dead = item_cl >= cvalid;
-        const unsigned oav = dead ? 0u : offa_v, oae = dead ? 0u : offa_e, obv = dead ? 0u : offb_v, obe = dead ? 0u : offb_e;
-        va_r = *(const f32x4*)(br + oav);
-        va_i = *(const f32x4*)(bi + oav);
-        ea_r = br[oae];
-        ea_i = bi[oae];
-        vb_r = *(const f32x4*)(br + obv);
-        vb_i = *(const f32x4*)(bi + obv);
-        eb_r = br[obe];
-        eb_i = bi[obe];
+        const bool dead = item_cl[i] >= cvalid;
+        const unsigned ov = dead ? 0u : off_v[i], oe = dead ? 0u : off_e[i];
+        v_r[i] = *(const f32x4*)(br + ov);
+        v_i[i] = *(const f32x4*)(bi + ov);
+        e_r[i] = br[oe];
+        e_i[i] = bi[oe];
     };
-    auto stage_store = [&](float* dst, int chunk) {
+    // the store of an item in ten steps that the main loop deals out between MFMAs (step 0: masks and the window of five columns;
+    // steps 1 .. 9: one (Gauss, time) plane each), so that the vector ALU work hides behind the matrix pipe
+    float fr[5], fi[5];
+    auto stage_window = [&](int chunk, int i) {
         const int ci0s = chunk * CIK;
         const int cvalid = (ci0s < a.C0 ? a.C0 : Cin) - ci0s;
-        unsigned m = okmask;
-        if (item_cl >= cvalid) m &= ~0x7fu;
-        const bool ra_ok = (m >> 5) & 1u, rb_ok = (m >> 6) & 1u;
-        const bool left = a.tshift != 0;
-        float fr[5], fi[5];
+        constexpr bool left = LEFT;
+        if (interior[i] && cvalid >= CIK) {                   // (uniform) nothing to mask
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int vi_ = left ? i - 1 : i;                 // index into the vector slot; the extra column is w0 (left) or w4
-            const bool ext = left ? i == 0 : i == 4;
-            const float ar = ext ? ea_r : va_r[vi_ & 3], ai = ext ? ea_i : va_i[vi_ & 3];
-            const float br_ = ext ? eb_r : vb_r[vi_ & 3], bi_ = ext ? eb_i : vb_i[vi_ & 3];
-            const bool cok = (m >> i) & 1u;
-            const float xa_r = (cok && ra_ok) ? ar : 0.f, xa_i = (cok && ra_ok) ? ai : 0.f;
-            const float xb_r = (cok && rb_ok) ? br_ : 0.f, xb_i = (cok && rb_ok) ? bi_ : 0.f;
-            fr[i] = xa_r + cbv * xb_r;
-            fi[i] = xa_i + cbv * xb_i;
-        }
-        if ((m >> 7) & 1u) {
-            float* d = dst + ldsoff;
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                float x[5];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) x[i] = g == 0 ? fr[i] + fi[i] : (g == 1 ? fr[i] : fi[i]);
-                // pair 0: (a, b, d) = x0, x1, x2; pair 1: x2, x3, x4
-                *(float2*)(d + (g * 3 + 0) * 32) = make_float2(x[0] - x[1], x[2] - x[3]);
-                *(float2*)(d + (g * 3 + 1) * 32) = make_float2(x[1], x[3]);
-                *(float2*)(d + (g * 3 + 2) * 32) = make_float2(x[1] - x[2], x[3] - x[4]);
+            for (int q = 0; q < 5; ++q) {
+                fr[q] = left ? (q == 0 ? e_r[i] : v_r[i][q == 0 ? 0 : q - 1]) : (q == 4 ? e_r[i] : v_r[i][q == 4 ? 3 : q]);
+                fi[q] = left ? (q == 0 ? e_i[i] : v_i[i][q == 0 ? 0 : q - 1]) : (q == 4 ? e_i[i] : v_i[i][q == 4 ? 3 : q]);
             }
+            return;
+        }
+        unsigned m = okmask[i];
+        if (item_cl[i] >= cvalid || !((m >> 5) & 1u)) m &= ~0x1fu;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            // window column q: the extra column is w0 (taps to the left) or w4; compile-time vector indices on either side
+            const float xr = left ? (q == 0 ? e_r[i] : v_r[i][q == 0 ? 0 : q - 1]) : (q == 4 ? e_r[i] : v_r[i][q == 4 ? 3 : q]);
+            const float xi = left ? (q == 0 ? e_i[i] : v_i[i][q == 0 ? 0 : q - 1]) : (q == 4 ? e_i[i] : v_i[i][q == 4 ? 3 : q]);
+            const bool cok = (m >> q) & 1u;
+            fr[q] = cok ? xr : 0.f;
+            fi[q] = cok ? xi : 0.f;
+        }
+    };
+    auto plane_val = [&](int gt, int pr) -> float {           // plane gt = g * 3 + tau of column pair pr (0 / 1) of the item
+        const int g = gt / 3, tau = gt - g * 3;
+        // pair 0: (a, b, d) = window columns 0, 1, 2; pair 1: 2, 3, 4
+        const int q0 = 2 * pr;
+        const float xa_ = g == 0 ? fr[q0] + fi[q0] : (g == 1 ? fr[q0] : fi[q0]);
+        const float xb_ = g == 0 ? fr[q0 + 1] + fi[q0 + 1] : (g == 1 ? fr[q0 + 1] : fi[q0 + 1]);
+        const float xd_ = g == 0 ? fr[q0 + 2] + fi[q0 + 2] : (g == 1 ? fr[q0 + 2] : fi[q0 + 2]);
+        return tau == 0 ? xa_ - xb_ : (tau == 1 ? xb_ : xb_ - xd_);
+    };
+    // an item exists for every thread in the even-row phase (512 items); in the odd-row phase the second item only in waves 0, 1
+    auto item_exists = [&](int i) -> bool { return NITEM >= (i + 1) * 256 || wave * 64 + i * 256 < NITEM; };
+    // flat layout (odd-row phase): plane gt at [gt][32 pairs]; one 8-byte write per plane
+    auto stage_plane = [&](float* dst, int i, int gt) {
+        if (!item_exists(i)) return;                          // (uniform)
+        *(float2*)(dst + ldsoff[i] + gt * 32) = make_float2(plane_val(gt, 0), plane_val(gt, 1));
+    };
+    // paired layout (even-row phase): planes (2 j, 2 j + 1) interleaved per column pair at [j][32 pairs][2], plane 8 at [256 + pair]:
+    // a lane fetches the operands of two tiles with one 8-byte read, an item writes two planes x two pairs with one 16-byte write
+    auto stage_plane2 = [&](float* dst, int i, int j) {
+        if (j < 4) {
+            f32x4 o = {plane_val(2 * j, 0), plane_val(2 * j + 1, 0), plane_val(2 * j, 1), plane_val(2 * j + 1, 1)};
+            *(f32x4*)(dst + ldsoff[i] + j * 64) = o;
+        } else {
+            *(float2*)(dst + ldsoff[i] - 2 * (int)(tid & 15) + 256) = make_float2(plane_val(8, 0), plane_val(8, 1));
+        }
+    };
+    auto stage_store = [&](float* dst, int chunk, int i) {
+        stage_window(chunk, i);
+        if (CONTIG) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) stage_plane2(dst, i, j);
+        } else {
+#pragma unroll
+            for (int gt = 0; gt < 9; ++gt) stage_plane(dst, i, gt);
         }
     };
 
-    // ---- weights: one 4-byte load per tile, channel pair and lane (lane = channel parity x 32 + co), in a ring of KS channel pairs
+    // ---- weights in a ring of RDW k-steps.  Odd-row phase: one 4-byte load per tile, channel pair and lane (lane = channel parity x 32
+    // + co).  Even-row phase: the wave's nine tiles of a channel pair are packed as two groups of [64 lanes][4 tiles] + one of [64
+    // lanes] (idv_pack_cconv_tw): two 16-byte loads + one 4-byte load per k-step instead of nine
     const float* wbase = a.wfrag + ((size_t)(PH == 1 ? (size_t)a.cotiles * a.UP * tw_ntp<0>() : 0) + (size_t)ct * a.UP * NTP) * 64 +
-                         (size_t)wave * 64 + lane;
+                         (CONTIG ? (size_t)wave * NTW * 64 : (size_t)wave * 64 + lane);
     const int total_ks = nchunk * KS;
-    float a_w[KS][NTW];
+    float a_w[RDW][NTW];
     auto load_w = [&](int g, float (&dst)[NTW]) {
         g = g < total_ks ? g : total_ks - 1;                  // (past the end of K: an unused re-fetch)
         const float* ws = wbase + (size_t)g * NTP * 64;
+        if (CONTIG) {
+            const f32x4 w0 = *(const f32x4*)(ws + lane * 4), w1 = *(const f32x4*)(ws + 256 + lane * 4);
 #pragma unroll
-        for (int k = 0; k < NTW; ++k) dst[k] = ws[(wave + 4 * k < NTP ? 4 * k : 0) * 64];
+            for (int k = 0; k < 4; ++k) {
+                dst[k] = w0[k];
+                dst[4 + k] = w1[k];
+            }
+            dst[NTW - 1] = ws[512 + lane];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NTW; ++k) dst[k] = ws[(wave + 4 * k < NTP ? 4 * k : 0) * 64];
+        }
     };
-    auto load_b = [&](const float* P, int ul, float (&dst)[NTW]) {
-        const float* row = P + (size_t)((2 * ul + half) * NT + wave) * 32 + l31;
+    float xa[NTW], xb[NTW];
+    // operands of tile k (flat layout) / of tiles 2 j, 2 j + 1 or tile 8 (paired layout); base = buffer + channel of this half-wave
+    auto load_raw1 = [&](const float* base, int k) {
+        xa[k] = base[offA[k] + l31];
+        xb[k] = base[offB[k] + l31];
+    };
+    auto load_raw2 = [&](const float* base, int j) {
+        if (j < 4) {
+            const float2 pa_ = *(const float2*)(base + offA[0] + j * 64 + 2 * l31), pb_ = *(const float2*)(base + offB[0] + j * 64 + 2 * l31);
+            xa[2 * j] = pa_.x; xa[2 * j + 1] = pa_.y;
+            xb[2 * j] = pb_.x; xb[2 * j + 1] = pb_.y;
+        } else {
+            xa[NTW - 1] = base[offA[0] + 256 + l31];
+            xb[NTW - 1] = base[offB[0] + 256 + l31];
+        }
+    };
+    auto load_raw_all = [&](const float* base) {
+        if (CONTIG) {
 #pragma unroll
-        for (int k = 0; k < NTW; ++k) dst[k] = row[(wave + 4 * k < NT ? 4 * k : 0) * 32];
+            for (int j = 0; j < 5; ++j) load_raw2(base, j);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NTW; ++k) load_raw1(base, k);
+        }
     };
 
-    stage_load(0);
 #pragma unroll
-    for (int u = 0; u < KS; ++u) load_w(u, a_w[u]);
-    stage_store(smem, 0);
-    stage_load(nchunk > 1 ? 1 : 0);
+    for (int i = 0; i < NLD; ++i) stage_load(0, i);
+#pragma unroll
+    for (int u = 0; u < RDW; ++u) load_w(u, a_w[u]);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) stage_store(smem, 0, i);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) stage_load(nchunk > 1 ? 1 : 0, i);
     __syncthreads();
 
-    float b_cur[NTW], b_nxt[NTW];
-    load_b(smem, 0, b_cur);
-    int ibuf = 0;
+    load_raw_all(smem + (size_t)half * RT);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-        const float* P = smem + ibuf * NE;
-        const int i1 = ibuf + 1 == NBUF ? 0 : ibuf + 1;
-        float* Pn = smem + i1 * NE;
+        const float* P = smem + (chunk & 1) * NE;
+        float* Pn = smem + ((chunk + 1) & 1) * NE;
+        const int nxt = chunk + 1 < nchunk ? chunk + 1 : chunk, nxt2 = chunk + 2 < nchunk ? chunk + 2 : nchunk - 1;
 #pragma unroll
         for (int ul = 0; ul < KS; ++ul) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[ul][0], b_cur[0], acc[0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ul == KS - 1) __syncthreads();                // every wave has stored chunk + 1 (at ul == 0): Pn is complete
-            if (ul + 1 < KS)
-                load_b(P, ul + 1, b_nxt);
-            else
-                load_b(Pn, 0, b_nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ul == 0) {
-                // the registers hold chunk + 1 (loaded one chunk ago); its buffer was last read two chunks ago, a barrier since
-                stage_store(Pn, chunk + 1 < nchunk ? chunk + 1 : chunk);
-                stage_load(chunk + 2 < nchunk ? chunk + 2 : nchunk - 1);
+            // operands of the next k-step: of this chunk, or (last k-step, after the barrier below) of the next chunk
+            const float* bnext = ul + 1 < KS ? P + (size_t)(2 * (ul + 1) + half) * RT : Pn + (size_t)half * RT;
+            // staging of chunk + 1 rides on k-steps 1 (item 0) and 2 (item 1): the item's registers were loaded one chunk ago, the
+            // other buffer was last read in the previous chunk (a barrier since); the steps of the store are dealt out between MFMAs
+            const int si = ul - 1;
+            const bool staging = !(DBG & 1) && si >= 0 && si < NLD;
+#pragma unroll
+            for (int k = 0; k < NTW; ++k) {
+                const float b = xa[k] + cbk[CONTIG ? 0 : k] * xb[k];
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[ul % RDW][k], b, acc[k], 0, 0, 0);
+                if (ul == KS - 1 && k == 0) {
+                    // every wave has stored chunk + 1 (k-steps 1, 2) and issued its last reads of P: after this barrier Pn is complete
+                    // and P may be overwritten (from k-step 1 of the next chunk on)
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                }
+                // the operand registers of the tiles done so far are free again
+                if (CONTIG) {
+                    if (k & 1) load_raw2(bnext, k >> 1);
+                    if (k == NTW - 1) load_raw2(bnext, 4);
+                } else {
+                    load_raw1(bnext, k);
+                }
+                if (staging) {
+                    if (k == 0) stage_window(nxt, si);
+                    if (CONTIG) {
+                        if (k & 1) stage_plane2(Pn, si, k >> 1);
+                        if (k == NTW - 1) stage_plane2(Pn, si, 4);
+                    } else {                                  // 7 tiles per wave: planes 0 .. 6 here, 7 and 8 with the last
+                        stage_plane(Pn, si, k);
+                        if (k == NTW - 1) {
+                            stage_plane(Pn, si, 7);
+                            stage_plane(Pn, si, 8);
+                        }
+                    }
+                    if (k == NTW - 1) stage_load(nxt2, si);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int k = 1; k < NTW; ++k)
-                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[ul][k], b_cur[k], acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_w((chunk + 1) * KS + ul, a_w[ul]);
-#pragma unroll
-            for (int k = 0; k < NTW; ++k) b_cur[k] = b_nxt[k];
+            if (!(DBG & 2)) load_w(chunk * KS + ul + RDW, a_w[ul % RDW]);
         }
-        ibuf = i1;
     }
     __syncthreads();                                          // all patch reads done: the buffers become the exchange area
 
@@ -268,11 +368,11 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
         keep[q] = inb[q] && tp >= 1 && tp <= a.t_valid;
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < ((DBG & 4) ? 1 : 4); ++s) {
         if (s > 0) __syncthreads();
 #pragma unroll
         for (int k = 0; k < NTW; ++k) {
-            const int t = wave + 4 * k;
+            const int t = CONTIG ? wave * NTW + k : wave + 4 * k;
             if (t < NT) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) E[(t * 4 + rr) * 64 + lane] = acc[k][4 * s + rr];
@@ -364,9 +464,17 @@ __global__ void pack_cconv_tw_kernel(const float* __restrict__ wino, int cotiles
         const int u = (int)(t_ % UP);
         const int ct = (int)(t_ / UP);
         float val = 0.f;
-        const int ci = 2 * u + (lane >> 5), co = lane & 31;
-        if (t < nt && ci * 3 < UN) {
-            const int r = t / 9, g = (t % 9) / 3, tau = t % 3;
+        int tt = t, ln = lane;
+        if (!ph) {
+            // even-row phase: per (pair u, frequency product r) two groups of [64 lanes][4 tiles] and one of [64 lanes]
+            const int w = (t * 64 + lane) % 576, r = (t * 64 + lane) / 576;
+            const int k = w < 512 ? (w >> 8) * 4 + (w & 3) : 8;
+            ln = w < 512 ? (w & 255) >> 2 : w - 512;
+            tt = r * 9 + k;
+        }
+        const int ci = 2 * u + (ln >> 5), co = ln & 31;
+        if (tt < nt && ci * 3 < UN) {
+            const int r = tt / 9, g = (tt % 9) / 3, tau = tt % 3;
             const float* src = wino + ((((size_t)ph * cotiles + ct) * UN + (size_t)ci * 3 + g) * 4 + r) * 64;
             const float w0 = src[co], w1 = src[32 + co];
             val = tau == 0 ? w0 : (tau == 1 ? w0 + w1 : w1);
@@ -375,10 +483,16 @@ __global__ void pack_cconv_tw_kernel(const float* __restrict__ wino, int cotiles
     }
 }
 
-template <int PH, int CIK>
+template <int PH, int CIK, bool LEFT, int DBG, int RDW>
+int launch_tw_ph_l(const TwArgs& a, hipStream_t st);
+template <int PH, int CIK, int DBG = 0, int RDW = 2>
 int launch_tw_ph(const TwArgs& a, hipStream_t st) {
-    constexpr int NE = CIK * tw_nt<PH>() * 32;
-    constexpr size_t smem = 3 * NE * sizeof(float);
+    return a.tshift ? launch_tw_ph_l<PH, CIK, true, DBG, RDW>(a, st) : launch_tw_ph_l<PH, CIK, false, DBG, RDW>(a, st);
+}
+template <int PH, int CIK, bool LEFT, int DBG, int RDW>
+int launch_tw_ph_l(const TwArgs& a, hipStream_t st) {
+    constexpr int NE = CIK * (PH == 0 ? 4 : 3) * 9 * 32;
+    constexpr size_t smem = 2 * NE * sizeof(float);
     static_assert(smem * 2 <= 160 * 1024, "the patch buffers of two workgroups must fit the 160 KB of LDS");
     TwArgs b = a;
     b.jtiles = (a.J + 63) / 64;
@@ -386,7 +500,7 @@ int launch_tw_ph(const TwArgs& a, hipStream_t st) {
     if (b.ftiles == 0) return IDV_OK;
     const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.cotiles;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = cconv_tw_kernel<PH, CIK>;
+    auto k = cconv_tw_kernel<PH, CIK, LEFT, DBG, RDW>;
     if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return IDV_ELAUNCH;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), smem, st, b);
@@ -395,11 +509,11 @@ int launch_tw_ph(const TwArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// 1 if idv_ctconv2d_tw_fwd serves the layer: what cgemm_wino's transposed form serves, with C0 a multiple of 4 when there is a
-// second source (a K chunk of 4 channels never straddles the sources)
+// 1 if idv_ctconv2d_tw_fwd serves the layer: what cgemm_wino's transposed form serves, with C0 a multiple of 8 when there is a
+// second source (a K chunk of 8 channels never straddles the sources)
 extern "C" int idv_cconv_tw_supported(int C0, int C1, int Cout, int Fin) {
     if (!idv_cconv_wino_supported(1, C0, C1, Cout, Fin)) return 0;
-    return (C1 == 0 || C0 % 4 == 0) ? 1 : 0;
+    return (C1 == 0 || C0 % 8 == 0) ? 1 : 0;
 }
 
 extern "C" long long idv_cconv_tw_wfrag_floats(int Cout, int cin_used) {
@@ -442,8 +556,20 @@ extern "C" int idv_ctconv2d_tw_fwd(const float* x0, int C0, const float* x1, int
     a.Cout = Cout; a.cotiles = (Cout + 31) / 32;
     a.tshift = tshift; a.t_valid = t_valid_out;
     if (Jp < a.J) return IDV_EINVAL;
-    if ((long long)4 * Fin * (long long)Jp >= 0xffffffffLL) return IDV_EINVAL;
+    if ((long long)8 * Fin * (long long)Jp >= 0xffffffffLL) return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = launch_tw_ph<0, 4>(a, st)) return rc;
-    return launch_tw_ph<1, 4>(a, st);
+    static const int dbg = [] { const char* e = getenv("IDV_TW_DBG"); return e ? atoi(e) : 0; }();
+    static const int only = [] { const char* e = getenv("IDV_TW_ONLY"); return e ? atoi(e) : 0; }();      // 1 / 2: one phase only
+    if (dbg) {
+        int rc = 0;
+        if (only != 2) rc = dbg == 1 ? launch_tw_ph<0, 8, 1>(a, st) : (dbg == 2 ? launch_tw_ph<0, 8, 2>(a, st) : launch_tw_ph<0, 8, 3>(a, st));
+        if (rc) return rc;
+        if (only != 1) rc = dbg == 1 ? launch_tw_ph<1, 8, 1>(a, st) : (dbg == 2 ? launch_tw_ph<1, 8, 2>(a, st) : launch_tw_ph<1, 8, 3>(a, st));
+        return rc;
+    }
+    static const int rdw = [] { const char* e = getenv("IDV_TW_RDW"); return e ? atoi(e) : 2; }();      // (experiments) weight ring depth
+    if (only != 2)
+        if (int rc = (rdw == 4 ? launch_tw_ph<0, 8, 0, 4>(a, st) : launch_tw_ph<0, 8>(a, st))) return rc;
+    if (only == 1) return IDV_OK;
+    return rdw == 4 ? launch_tw_ph<1, 8, 0, 4>(a, st) : launch_tw_ph<1, 8>(a, st);
 }

@@ -602,7 +602,7 @@ int idv_cconv2d_wino_fwd(const float* x0, int C0, const float* x1, int C1, const
  * x 3/4 = 0.39 of the reference's real products.  Same result up to the rounding of the transforms.  idv_pack_cconv_tw re-orders
  * the fragments of idv_pack_cconv_wino(transposed = 1) (wino_frag) into idv_cconv_tw_wfrag_floats floats; epi / has_fold from
  * idv_pack_cconv_gauss.  No statistics, no addend (the evaluation forward and the data gradients).  Sources at pitch Jp
- * (Jp % 4 == 0, 16-byte aligned), C0 % 4 == 0 with a second source. */
+ * (Jp % 4 == 0, 16-byte aligned), C0 % 8 == 0 with a second source. */
 int idv_cconv_tw_supported(int C0, int C1, int Cout, int Fin);
 long long idv_cconv_tw_wfrag_floats(int Cout, int cin_used);
 int idv_pack_cconv_tw(const float* wino_frag, int Cout, int cin_used, float* tw_frag, void* stream);
