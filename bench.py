@@ -379,6 +379,9 @@ def kernel_name(cfg_id):
         return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
     if cfg_id == 1000001:
         return "void (anonymous namespace)::ctconv_c1_f32_kernel<false>(CgemmArgs, int)"
+    if cfg_id in (5000000, 5000001):      # ops.TW_CFG (+ 1: taps to the left): the two phase kernels of a transposed-conv layer
+        a, b = kernel_parts(cfg_id)
+        return a.replace("((anonymous namespace)::TwArgs)", "") + " + " + b.replace("void (anonymous namespace)::cconv_tw_kernel", "")
     if 4000000 <= cfg_id < 5000000:       # ops.WINO_CFG + 1000 * transposed + idv_cconv_wino_config digits WM WN CIK
         tr, d = (cfg_id - 4000000) // 1000, str((cfg_id - 4000000) % 1000)
         if tr:                                # the two phase kernels of a transposed-conv layer (+ their half-tile variants)
@@ -411,6 +414,10 @@ def kernel_name(cfg_id):
 def kernel_parts(cfg_id):
     """The kernel name(s), as rocprofv3 prints them, behind one timed launch of configuration cfg_id: one name, except for a
     transposed-conv layer on the Winograd form (even-row phase kernel + odd-row phase kernel)."""
+    if cfg_id in (5000000, 5000001):
+        left = "true" if cfg_id == 5000001 else "false"
+        return [f"void (anonymous namespace)::cconv_tw_kernel<0, 8, {left}, 0, 2, true>((anonymous namespace)::TwArgs)",
+                f"void (anonymous namespace)::cconv_tw_kernel<1, 8, {left}, 0, 2, false>((anonymous namespace)::TwArgs)"]
     if 4001000 <= cfg_id < 5000000:
         d = str((cfg_id - 4000000) % 1000)
         # even-row phase at two workgroups per CU: four channels per chunk (4 x 1 waves) / two (2 x 2)
@@ -475,6 +482,16 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
                           "(Gauss) x 7 of 10 frequency-tap products (Winograd F(2,3) + F(2,2)): `executed` = 0.525 x achieved, "
                           "excluding the padding row of an odd row count.  One `launch` here = one decoder layer = the even-row and the odd-row "
                           "phase kernel back to back (kernel_parts): avg_launch_ms = the sum of their average durations in the rocprofv3 summary")
+    if dom in (5000000, 5000001):
+        # time-Winograd on top (cgemm_tw.hip): 3 of 4 products per pair of output columns as well
+        r["executed"] = round(0.525 * 0.75 * ach, 3)
+        r["frac_executed"] = round(0.525 * 0.75 * ach / peak, 4)
+        r["peak_note"] = ("dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32); achieved counts ALGORITHMIC flops (the reference's 4 real "
+                          "convolutions x 10 taps per complex transposed convolution, SURVEY 8(d)); the kernels execute 3 real products "
+                          "(Gauss) x 7 of 10 frequency-tap products (Winograd F(2,3) + F(2,2)) x 3 of 4 time-tap products (F(2,2) over "
+                          "pairs of output columns): `executed` = 0.394 x achieved, excluding padding (the last row pair of an odd row "
+                          "count, the 28th tile slot of the odd-row phase).  One `launch` here = one decoder layer = the even-row and "
+                          "the odd-row phase kernel back to back (kernel_parts)")
     if 3000000 <= dom < 4000000 or dom == -95:
         # three real products per complex product (Gauss, cgemm_gauss.hip): `achieved` counts the reference's 4 real convolutions
         r["executed"] = round(0.75 * ach, 3)

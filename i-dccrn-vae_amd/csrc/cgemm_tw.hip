@@ -30,7 +30,7 @@ struct TwArgs {
     int C0, C1;
     int Fin, Fout;
     int J, Jp, Tp;
-    const float* wfrag;   // [phase 0: cotiles][UP][36][64] then [phase 1: cotiles][UP][28][64]
+    const float* wfrag;   // [phase 0: cotiles][UP][4 waves x 9 slots][64] then [phase 1: cotiles][UP][4 x 8][64] (idv_pack_cconv_tw)
     int UP;               // channel pairs per co tile as packed (Cin rounded up to the pack granularity, / 2)
     const float* epi;     // as cgemm_gauss: [cotiles * 32][8]
     int has_fold;
@@ -58,12 +58,21 @@ template <int PH> __device__ __forceinline__ float tw_cb(int r) {
 }
 template <int PH> constexpr int tw_nr() { return PH == 0 ? 4 : 3; }
 template <int PH> constexpr int tw_nt() { return tw_nr<PH>() * 9; }            // tiles (r, g, tau): t = r * 9 + g * 3 + tau
-template <int PH> constexpr int tw_ntp() { return PH == 0 ? 36 : 28; }         // tile slots per channel pair in the packed weights
-template <int PH> constexpr int tw_ntw() { return (tw_nt<PH>() + 3) / 4; }     // tiles per wave
+template <int PH> constexpr int tw_ntp() { return PH == 0 ? 36 : 32; }         // weight slots per channel pair: 4 waves x 9 / 8
+template <int PH> constexpr int tw_ntw() { return (tw_nt<PH>() + 3) / 4; }     // tiles per wave: 9 / 7
+// tile k of wave w: t = r * 9 + plane, or -1 (the odd-row phase's 28th slot: zero taps, never read).  Tiles come as NPAIR pairs of
+// planes (2 p, 2 p + 1) of ONE frequency product + one single tile (plane 8): even-row phase, wave = r: all nine planes of r.
+// Odd-row phase: waves 0 .. 2 = r: planes 0 .. 5 and 8; wave 3: planes 6, 7 of r = 0, 1, 2.
+__host__ __device__ inline int tw_tile(int ph, int w, int k) {
+    if (ph == 0) return w * 9 + k;
+    if (w < 3) return k < 6 ? w * 9 + k : w * 9 + 8;
+    return k < 6 ? (k >> 1) * 9 + 6 + (k & 1) : -1;
+}
+template <int PH> constexpr int tw_wslots() { return PH == 0 ? 9 : 8; }        // packed weight slots per (channel pair, wave)
 
 // DBG (timing experiments only, results wrong): 1 = no staging after the prologue, 2 = no weight re-loads, 4 = no epilogue exchange
 // LEFT: the time taps read (x[t-1], x[t]) (tshift = -1: the extra window column is on the left), else (x[t], x[t+1])
-template <int PH, int CIK, bool LEFT, int DBG = 0, int RDW = 2>
+template <int PH, int CIK, bool LEFT, int DBG = 0, int RDW = 2, bool WVEC = true>
 __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
     constexpr int NR = tw_nr<PH>(), NT = tw_nt<PH>(), NTP = tw_ntp<PH>(), NTW = tw_ntw<PH>();
     constexpr int NRAW = PH == 0 ? 4 : 3, ROW0 = PH == 0 ? 0 : 1;       // raw patch rows d(ROW0) .. : input rows m0 - 1 + ROW0 ..
@@ -104,26 +113,27 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
     for (int k = 0; k < NTW; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-    // this wave's tiles.  Even-row phase: wave = frequency product r, tiles t = 9 r + k (k = the 9 (Gauss, time) planes): the LDS
-    // offsets of its operands are one base + compile-time constants.  Odd-row phase: 27 tiles on 4 waves, dealt round-robin
-    // t = wave + 4 k (7 per wave; the 28th slot has zero taps), offsets per tile.  The B operand of tile (r, g, tau) is plane
-    // (g, tau) of raw row ra(r) + cb(r) x the same plane of raw row rb(r) -- the frequency transform at the operand read.  In a half
-    // tile the products r = 3 do work nobody reads (they only feed the missing output row), branch-free.
-    constexpr bool CONTIG = PH == 0;
-    int offA[CONTIG ? 1 : NTW], offB[CONTIG ? 1 : NTW];
-    float cbk[CONTIG ? 1 : NTW];
-    if (CONTIG) {
-        cbk[0] = tw_cb<PH>(wave);
-        offA[0] = (tw_ra<PH>(wave) - ROW0) * 9 * 32;
-        offB[0] = (tw_rb<PH>(wave) - ROW0) * 9 * 32;      // (cb is never 0 in this phase)
+    // this wave's tiles (tw_tile): NPAIR pairs of planes + one single; slot j of the wave reads raw rows ra(r_j), rb(r_j) at plane pair
+    // pj_j -- the frequency transform  A + cb B  happens at the operand read.  In a half tile the products r = 3 do work nobody reads
+    // (they only feed the missing output row), branch-free.
+    constexpr int NPAIR = (NTW - 1) / 2;
+    constexpr bool UNI = PH == 0;             // every slot of the wave belongs to ONE frequency product: one row offset, constant plane offsets
+    int offA[UNI ? 1 : NPAIR + 1], offB[UNI ? 1 : NPAIR + 1];
+    float cbj[UNI ? 1 : NPAIR + 1];
+    if (UNI) {
+        cbj[0] = tw_cb<PH>(wave);
+        offA[0] = (tw_ra<PH>(wave) - ROW0) * 288;
+        offB[0] = (tw_rb<PH>(wave) - ROW0) * 288;             // (cb is never 0 in this phase)
     } else {
 #pragma unroll
-        for (int k = 0; k < NTW; ++k) {
-            const int t = wave + 4 * k < NT ? wave + 4 * k : 0;
-            const int r = t / 9, gt = t - r * 9;
-            cbk[k] = tw_cb<PH>(r);
-            offA[k] = ((tw_ra<PH>(r) - ROW0) * 9 + gt) * 32;
-            offB[k] = cbk[k] != 0.f ? ((tw_rb<PH>(r) - ROW0) * 9 + gt) * 32 : offA[k];
+        for (int j = 0; j <= NPAIR; ++j) {
+            int t = tw_tile(PH, wave, j < NPAIR ? 2 * j : NTW - 1);
+            t = t < 0 ? 0 : t;
+            const int r = t / 9, plane = t - r * 9;
+            cbj[j] = tw_cb<PH>(r);
+            const int po = plane == 8 ? 256 : (plane >> 1) * 64;
+            offA[j] = (tw_ra<PH>(r) - ROW0) * 288 + po;
+            offB[j] = cbj[j] != 0.f ? (tw_rb<PH>(r) - ROW0) * 288 + po : offA[j];
         }
     }
 
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
         if (!(je >= 0 && je < a.Jp)) m &= LEFT ? ~1u : ~(1u << 4);
         okmask[i] = m;
         interior[i] = __builtin_amdgcn_ballot_w64((m & 0xbfu) == 0xbfu) == ~0ull;
-        ldsoff[i] = (unsigned)((cl * NRAW + rl) * 9 * 32 + (PH == 0 ? 4 : 2) * c8);
+        ldsoff[i] = (unsigned)((cl * NRAW + rl) * 288 + 4 * c8);
     }
     auto stage_load = [&](int chunk, int i) {
         const int ci0 = chunk * CIK;
@@ -216,14 +226,10 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
     };
     // an item exists for every thread in the even-row phase (512 items); in the odd-row phase the second item only in waves 0, 1
     auto item_exists = [&](int i) -> bool { return NITEM >= (i + 1) * 256 || wave * 64 + i * 256 < NITEM; };
-    // flat layout (odd-row phase): plane gt at [gt][32 pairs]; one 8-byte write per plane
-    auto stage_plane = [&](float* dst, int i, int gt) {
-        if (!item_exists(i)) return;                          // (uniform)
-        *(float2*)(dst + ldsoff[i] + gt * 32) = make_float2(plane_val(gt, 0), plane_val(gt, 1));
-    };
-    // paired layout (even-row phase): planes (2 j, 2 j + 1) interleaved per column pair at [j][32 pairs][2], plane 8 at [256 + pair]:
+    // LDS layout of a raw row: planes (2 j, 2 j + 1) interleaved per column pair at [j][32 pairs][2], plane 8 at [256 + pair]:
     // a lane fetches the operands of two tiles with one 8-byte read, an item writes two planes x two pairs with one 16-byte write
     auto stage_plane2 = [&](float* dst, int i, int j) {
+        if (!item_exists(i)) return;                          // (uniform)
         if (j < 4) {
             f32x4 o = {plane_val(2 * j, 0), plane_val(2 * j + 1, 0), plane_val(2 * j, 1), plane_val(2 * j + 1, 1)};
             *(f32x4*)(dst + ldsoff[i] + j * 64) = o;
@@ -233,62 +239,50 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
     };
     auto stage_store = [&](float* dst, int chunk, int i) {
         stage_window(chunk, i);
-        if (CONTIG) {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) stage_plane2(dst, i, j);
-        } else {
-#pragma unroll
-            for (int gt = 0; gt < 9; ++gt) stage_plane(dst, i, gt);
-        }
+        for (int j = 0; j < 5; ++j) stage_plane2(dst, i, j);
     };
 
-    // ---- weights in a ring of RDW k-steps.  Odd-row phase: one 4-byte load per tile, channel pair and lane (lane = channel parity x 32
-    // + co).  Even-row phase: the wave's nine tiles of a channel pair are packed as two groups of [64 lanes][4 tiles] + one of [64
-    // lanes] (idv_pack_cconv_tw): two 16-byte loads + one 4-byte load per k-step instead of nine
+    // ---- weights in a ring of RDW k-steps: the wave's tiles of a channel pair are packed as groups of [64 lanes][4 tiles] (lane =
+    // channel parity x 32 + co; idv_pack_cconv_tw): even-row phase two 16-byte loads + one 4-byte load ([64 lanes]) per k-step,
+    // odd-row phase two 16-byte loads
+    constexpr int WS = tw_wslots<PH>();
     const float* wbase = a.wfrag + ((size_t)(PH == 1 ? (size_t)a.cotiles * a.UP * tw_ntp<0>() : 0) + (size_t)ct * a.UP * NTP) * 64 +
-                         (CONTIG ? (size_t)wave * NTW * 64 : (size_t)wave * 64 + lane);
+                         (size_t)wave * WS * 64;
     const int total_ks = nchunk * KS;
     float a_w[RDW][NTW];
     auto load_w = [&](int g, float (&dst)[NTW]) {
         g = g < total_ks ? g : total_ks - 1;                  // (past the end of K: an unused re-fetch)
         const float* ws = wbase + (size_t)g * NTP * 64;
-        if (CONTIG) {
+        if (WVEC) {
             const f32x4 w0 = *(const f32x4*)(ws + lane * 4), w1 = *(const f32x4*)(ws + 256 + lane * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 dst[k] = w0[k];
-                dst[4 + k] = w1[k];
+                if (4 + k < NTW) dst[4 + k] = w1[k];
             }
-            dst[NTW - 1] = ws[512 + lane];
-        } else {
+            if (NTW == 9) dst[NTW - 1] = ws[512 + lane];
+        } else {                                              // (experiments) slot-major [slot][64 lanes]: one 4-byte load per tile
 #pragma unroll
-            for (int k = 0; k < NTW; ++k) dst[k] = ws[(wave + 4 * k < NTP ? 4 * k : 0) * 64];
+            for (int k = 0; k < NTW; ++k) dst[k] = ws[k * 64 + lane];
         }
     };
     float xa[NTW], xb[NTW];
-    // operands of tile k (flat layout) / of tiles 2 j, 2 j + 1 or tile 8 (paired layout); base = buffer + channel of this half-wave
-    auto load_raw1 = [&](const float* base, int k) {
-        xa[k] = base[offA[k] + l31];
-        xb[k] = base[offB[k] + l31];
-    };
+    // operands of tiles 2 j, 2 j + 1 (j < NPAIR: one 8-byte read per raw row) or of the single tile; base = buffer + channel of this half-wave
     auto load_raw2 = [&](const float* base, int j) {
-        if (j < 4) {
-            const float2 pa_ = *(const float2*)(base + offA[0] + j * 64 + 2 * l31), pb_ = *(const float2*)(base + offB[0] + j * 64 + 2 * l31);
+        if (j < NPAIR) {
+            const int oa = UNI ? offA[0] + j * 64 : offA[UNI ? 0 : j], ob = UNI ? offB[0] + j * 64 : offB[UNI ? 0 : j];
+            const float2 pa_ = *(const float2*)(base + oa + 2 * l31), pb_ = *(const float2*)(base + ob + 2 * l31);
             xa[2 * j] = pa_.x; xa[2 * j + 1] = pa_.y;
             xb[2 * j] = pb_.x; xb[2 * j + 1] = pb_.y;
         } else {
-            xa[NTW - 1] = base[offA[0] + 256 + l31];
-            xb[NTW - 1] = base[offB[0] + 256 + l31];
+            xa[NTW - 1] = base[(UNI ? offA[0] + 256 : offA[UNI ? 0 : NPAIR]) + l31];
+            xb[NTW - 1] = base[(UNI ? offB[0] + 256 : offB[UNI ? 0 : NPAIR]) + l31];
         }
     };
     auto load_raw_all = [&](const float* base) {
-        if (CONTIG) {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) load_raw2(base, j);
-        } else {
-#pragma unroll
-            for (int k = 0; k < NTW; ++k) load_raw1(base, k);
-        }
+        for (int j = 0; j <= NPAIR; ++j) load_raw2(base, j);
     };
 
 #pragma unroll
@@ -316,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
             const bool staging = !(DBG & 1) && si >= 0 && si < NLD;
 #pragma unroll
             for (int k = 0; k < NTW; ++k) {
-                const float b = xa[k] + cbk[CONTIG ? 0 : k] * xb[k];
+                const float b = xa[k] + cbj[UNI ? 0 : (k >> 1 < NPAIR ? k >> 1 : NPAIR)] * xb[k];
                 acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[ul % RDW][k], b, acc[k], 0, 0, 0);
                 if (ul == KS - 1 && k == 0) {
                     // every wave has stored chunk + 1 (k-steps 1, 2) and issued its last reads of P: after this barrier Pn is complete
@@ -325,24 +319,14 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
                     __syncthreads();
                 }
                 // the operand registers of the tiles done so far are free again
-                if (CONTIG) {
-                    if (k & 1) load_raw2(bnext, k >> 1);
-                    if (k == NTW - 1) load_raw2(bnext, 4);
-                } else {
-                    load_raw1(bnext, k);
-                }
+                if ((k & 1) && (k >> 1) < NPAIR) load_raw2(bnext, k >> 1);
+                if (k == NTW - 1) load_raw2(bnext, NPAIR);
                 if (staging) {
+                    // the store's steps between the MFMAs: window at 0, plane pairs at 1, 3, 5 and (7 or, with seven tiles, 6), plane 8 last
                     if (k == 0) stage_window(nxt, si);
-                    if (CONTIG) {
-                        if (k & 1) stage_plane2(Pn, si, k >> 1);
-                        if (k == NTW - 1) stage_plane2(Pn, si, 4);
-                    } else {                                  // 7 tiles per wave: planes 0 .. 6 here, 7 and 8 with the last
-                        stage_plane(Pn, si, k);
-                        if (k == NTW - 1) {
-                            stage_plane(Pn, si, 7);
-                            stage_plane(Pn, si, 8);
-                        }
-                    }
+                    if ((k & 1) && k < 6) stage_plane2(Pn, si, k >> 1);
+                    if (k == (NTW == 9 ? 7 : 6)) stage_plane2(Pn, si, 3);
+                    if (k == NTW - 1) stage_plane2(Pn, si, 4);
                     if (k == NTW - 1) stage_load(nxt2, si);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -372,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
         if (s > 0) __syncthreads();
 #pragma unroll
         for (int k = 0; k < NTW; ++k) {
-            const int t = CONTIG ? wave * NTW + k : wave + 4 * k;
-            if (t < NT) {
+            const int t = tw_tile(PH, wave, k);
+            if (t >= 0) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) E[(t * 4 + rr) * 64 + lane] = acc[k][4 * s + rr];
             }
@@ -452,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
 // cgemm_wino's fragments [phase][ct][unit = ci * 3 + g][slot r (4)][lane = h * 32 + co] (h: the two time taps as the MFMA's two k,
 // h = 0 multiplies column j + tshift) -> [phase][ct][pair u][tile t = r * 9 + g * 3 + tau (36 | 28 slots)][lane = parity * 32 + co]
 // with the time-transformed taps  tau 0: W_h0,  tau 1: W_h0 + W_h1,  tau 2: W_h1.
-__global__ void pack_cconv_tw_kernel(const float* __restrict__ wino, int cotiles, int UN, int UP, float* __restrict__ out) {
+__global__ void pack_cconv_tw_kernel(const float* __restrict__ wino, int cotiles, int UN, int UP, int vec, float* __restrict__ out) {
     const long long n0 = (long long)cotiles * UP * tw_ntp<0>() * 64, n1 = (long long)cotiles * UP * tw_ntp<1>() * 64;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n0 + n1; idx += (long long)gridDim.x * blockDim.x) {
         const int ph = idx >= n0;
@@ -464,16 +448,15 @@ __global__ void pack_cconv_tw_kernel(const float* __restrict__ wino, int cotiles
         const int u = (int)(t_ % UP);
         const int ct = (int)(t_ / UP);
         float val = 0.f;
-        int tt = t, ln = lane;
-        if (!ph) {
-            // even-row phase: per (pair u, frequency product r) two groups of [64 lanes][4 tiles] and one of [64 lanes]
-            const int w = (t * 64 + lane) % 576, r = (t * 64 + lane) / 576;
-            const int k = w < 512 ? (w >> 8) * 4 + (w & 3) : 8;
-            ln = w < 512 ? (w & 255) >> 2 : w - 512;
-            tt = r * 9 + k;
-        }
+        // per (channel pair u, wave w) WS = 9 / 8 slots: groups of [64 lanes][4 tiles] (+ one of [64 lanes] in the even-row phase)
+        const int ws_ = ph ? tw_wslots<1>() : tw_wslots<0>();
+        const int pos = t * 64 + lane, w = pos / (ws_ * 64), q = pos % (ws_ * 64);
+        const bool vec_ = (vec >> ph) & 1;
+        const int k = !vec_ ? q >> 6 : (q < 512 ? (q >> 8) * 4 + (q & 3) : 8);
+        const int ln = !vec_ ? q & 63 : (q < 512 ? (q & 255) >> 2 : q - 512);
+        const int tt = k < (ph ? 7 : 9) ? tw_tile(ph, w, k) : -1;
         const int ci = 2 * u + (ln >> 5), co = ln & 31;
-        if (tt < nt && ci * 3 < UN) {
+        if (tt >= 0 && ci * 3 < UN) {
             const int r = tt / 9, g = (tt % 9) / 3, tau = tt % 3;
             const float* src = wino + ((((size_t)ph * cotiles + ct) * UN + (size_t)ci * 3 + g) * 4 + r) * 64;
             const float w0 = src[co], w1 = src[32 + co];
@@ -483,13 +466,23 @@ __global__ void pack_cconv_tw_kernel(const float* __restrict__ wino, int cotiles
     }
 }
 
-template <int PH, int CIK, bool LEFT, int DBG, int RDW>
+template <int PH, int CIK, bool LEFT, int DBG, int RDW, bool WVEC = true>
 int launch_tw_ph_l(const TwArgs& a, hipStream_t st);
+// weight fragments as [64 lanes][4 tiles] groups with 16-byte loads (bit PH set) or slot-major [slot][64 lanes] with 4-byte loads: measured
+// (B = 64, dec0-3) even-row phase 22.0 -> 21.1 ms with the vector form, odd-row phase 14.1 -> 17.8 ms: default 1 = even-row phase only
+// (IDV_TW_WVEC=0 .. 3 for experiments; read by the pack kernel and the launcher alike)
+inline int tw_wvec_mask() {
+    static const int v = [] { const char* e = getenv("IDV_TW_WVEC"); return e ? atoi(e) : 1; }();
+    return v;
+}
 template <int PH, int CIK, int DBG = 0, int RDW = 2>
 int launch_tw_ph(const TwArgs& a, hipStream_t st) {
+    const bool wv = (tw_wvec_mask() >> PH) & 1;
+    if (DBG == 0 && RDW == 2 && !wv)
+        return a.tshift ? launch_tw_ph_l<PH, CIK, true, 0, 2, false>(a, st) : launch_tw_ph_l<PH, CIK, false, 0, 2, false>(a, st);
     return a.tshift ? launch_tw_ph_l<PH, CIK, true, DBG, RDW>(a, st) : launch_tw_ph_l<PH, CIK, false, DBG, RDW>(a, st);
 }
-template <int PH, int CIK, bool LEFT, int DBG, int RDW>
+template <int PH, int CIK, bool LEFT, int DBG, int RDW, bool WVEC>
 int launch_tw_ph_l(const TwArgs& a, hipStream_t st) {
     constexpr int NE = CIK * (PH == 0 ? 4 : 3) * 9 * 32;
     constexpr size_t smem = 2 * NE * sizeof(float);
@@ -500,7 +493,7 @@ int launch_tw_ph_l(const TwArgs& a, hipStream_t st) {
     if (b.ftiles == 0) return IDV_OK;
     const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.cotiles;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = cconv_tw_kernel<PH, CIK, LEFT, DBG, RDW>;
+    auto k = cconv_tw_kernel<PH, CIK, LEFT, DBG, RDW, WVEC>;
     if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return IDV_ELAUNCH;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), smem, st, b);
@@ -518,7 +511,7 @@ extern "C" int idv_cconv_tw_supported(int C0, int C1, int Cout, int Fin) {
 
 extern "C" long long idv_cconv_tw_wfrag_floats(int Cout, int cin_used) {
     const long long cotiles = (Cout + 31) / 32, cpad = (cin_used + TW_PACK_CI - 1) / TW_PACK_CI * TW_PACK_CI;
-    return cotiles * (cpad / 2) * (36 + 28) * 64;
+    return cotiles * (cpad / 2) * (36 + 32) * 64;
 }
 
 // wino_frag: idv_pack_cconv_wino(transposed = 1) of the same weights; tw_frag: idv_cconv_tw_wfrag_floats floats
@@ -529,7 +522,7 @@ extern "C" int idv_pack_cconv_tw(const float* wino_frag, int Cout, int cin_used,
     const long long n = idv_cconv_tw_wfrag_floats(Cout, cin_used);
     const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(pack_cconv_tw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, wino_frag, cotiles, cpad * 3, cpad / 2,
-                       tw_frag);
+                       tw_wvec_mask(), tw_frag);
     return idv_launch_status();
 }
 
