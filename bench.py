@@ -416,8 +416,8 @@ def kernel_parts(cfg_id):
     transposed-conv layer on the Winograd form (even-row phase kernel + odd-row phase kernel)."""
     if cfg_id in (5000000, 5000001):
         left = "true" if cfg_id == 5000001 else "false"
-        return [f"void (anonymous namespace)::cconv_tw_kernel<0, 8, {left}, 0, 2, true>((anonymous namespace)::TwArgs)",
-                f"void (anonymous namespace)::cconv_tw_kernel<1, 8, {left}, 0, 2, false>((anonymous namespace)::TwArgs)"]
+        return [f"void (anonymous namespace)::cconv_tw_kernel<0, 8, {left}, 0, 2, true, false>((anonymous namespace)::TwArgs)",
+                f"void (anonymous namespace)::cconv_tw_kernel<1, 8, {left}, 0, 2, false, false>((anonymous namespace)::TwArgs)"]
     if 4001000 <= cfg_id < 5000000:
         d = str((cfg_id - 4000000) % 1000)
         # even-row phase at two workgroups per CU: four channels per chunk (4 x 1 waves) / two (2 x 2)

@@ -38,6 +38,10 @@ struct TwArgs {
     float* out;           // planar [2][Cout][Fout][Jp]
     int Cout, cotiles;
     int tshift, t_valid;
+    double* stats;        // train mode: [Cout][5] sums (r, i, rr, ii, ri) of the outputs, or nullptr (as cgemm_gauss)
+    int stats_rep;        // > 1: that many replicas [rep][Cout][5] (power of two), one chosen per workgroup
+    const float* add;     // optional addend (see cgemm_gauss.hip)
+    int add_div, add_Jp;
     int jtiles, ftiles;
 };
 
@@ -72,7 +76,7 @@ template <int PH> constexpr int tw_wslots() { return PH == 0 ? 9 : 8; }        /
 
 // DBG (timing experiments only, results wrong): 1 = no staging after the prologue, 2 = no weight re-loads, 4 = no epilogue exchange
 // LEFT: the time taps read (x[t-1], x[t]) (tshift = -1: the extra window column is on the left), else (x[t], x[t+1])
-template <int PH, int CIK, bool LEFT, int DBG = 0, int RDW = 2, bool WVEC = true>
+template <int PH, int CIK, bool LEFT, int DBG = 0, int RDW = 2, bool WVEC = true, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
     constexpr int NR = tw_nr<PH>(), NT = tw_nt<PH>(), NTP = tw_ntp<PH>(), NTW = tw_ntw<PH>();
     constexpr int NRAW = PH == 0 ? 4 : 3, ROW0 = PH == 0 ? 0 : 1;       // raw patch rows d(ROW0) .. : input rows m0 - 1 + ROW0 ..
@@ -344,12 +348,14 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
     float* E = smem;
     const int jA = j0 + 2 * l31;                              // the pair's two output columns jA, jA + 1
     bool keep[2], inb[2];
+    int ja[2];                                                // the addend's column: utterance b / add_div of its own buffer
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int j = jA + q;
-        const int tp = j % a.Tp;
+        const int bj = j / a.Tp, tp = j - bj * a.Tp;
         inb[q] = j < a.J;
         keep[q] = inb[q] && tp >= 1 && tp <= a.t_valid;
+        ja[q] = j - (bj - bj / a.add_div) * a.Tp;
     }
 #pragma unroll
     for (int s = 0; s < ((DBG & 4) ? 1 : 4); ++s) {
@@ -388,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
         const bool cok = co < a.Cout;
         const f32x4 e0 = *(const f32x4*)(a.epi + (size_t)co * 8);
         const float e4 = a.epi[(size_t)co * 8 + 4], e5 = a.epi[(size_t)co * 8 + 5];
+        float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int fo = 2 * m0 + PH + 2 * rt;
@@ -403,6 +410,10 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
                     re = rt == 0 ? pr[0][q] + pr[1][q] : pr[1][q] - pr[2][q];
                     im = rt == 0 ? pi[0][q] + pi[1][q] : pi[1][q] - pi[2][q];
                 }
+                if (a.add && cok && inb[q]) {
+                    re += a.add[((size_t)co * a.Fout + fo) * a.add_Jp + ja[q]];
+                    im += a.add[((size_t)(a.Cout + co) * a.Fout + fo) * a.add_Jp + ja[q]];
+                }
                 float r_, i_;
                 if (a.has_fold) {
                     r_ = e0[0] * re + e0[1] * im + e4;
@@ -417,6 +428,13 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
                 }
                 yr[q] = keep[q] ? r_ : 0.f;
                 yi[q] = keep[q] ? i_ : 0.f;
+                if (STATS && keep[q]) {
+                    st[0] += yr[q];
+                    st[1] += yi[q];
+                    st[2] += yr[q] * yr[q];
+                    st[3] += yi[q] * yi[q];
+                    st[4] += yr[q] * yi[q];
+                }
             }
             if (cok) {
                 float* o_r = a.out + ((size_t)co * a.Fout + fo) * a.Jp + jA;
@@ -428,6 +446,17 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
                     o_r[0] = yr[0];
                     o_i[0] = yi[0];
                 }
+            }
+        }
+        if (STATS) {
+            // the 32 lanes of a half-wave hold the 32 column pairs of ONE output channel
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                float tsum = st[q];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o, 64);
+                if (l31 == 0 && cok)
+                    atomicAdd(&a.stats[((size_t)(a.stats_rep > 1 ? (blockIdx.x & (a.stats_rep - 1)) : 0) * a.Cout + co) * 5 + q], (double)tsum);
             }
         }
     }
@@ -466,7 +495,7 @@ __global__ void pack_cconv_tw_kernel(const float* __restrict__ wino, int cotiles
     }
 }
 
-template <int PH, int CIK, bool LEFT, int DBG, int RDW, bool WVEC = true>
+template <int PH, int CIK, bool LEFT, int DBG, int RDW, bool WVEC = true, bool STATS = false>
 int launch_tw_ph_l(const TwArgs& a, hipStream_t st);
 // weight fragments as [64 lanes][4 tiles] groups with 16-byte loads (bit PH set) or slot-major [slot][64 lanes] with 4-byte loads: measured
 // (B = 64, dec0-3) even-row phase 22.0 -> 21.1 ms with the vector form, odd-row phase 14.1 -> 17.8 ms: default 1 = even-row phase only
@@ -478,11 +507,16 @@ inline int tw_wvec_mask() {
 template <int PH, int CIK, int DBG = 0, int RDW = 2>
 int launch_tw_ph(const TwArgs& a, hipStream_t st) {
     const bool wv = (tw_wvec_mask() >> PH) & 1;
+    if (DBG == 0 && RDW == 2 && a.stats) {                    // the training forward: default weight layouts only
+        constexpr bool WV = PH == 0;
+        if (wv != WV) return IDV_EINVAL;
+        return a.tshift ? launch_tw_ph_l<PH, CIK, true, 0, 2, WV, true>(a, st) : launch_tw_ph_l<PH, CIK, false, 0, 2, WV, true>(a, st);
+    }
     if (DBG == 0 && RDW == 2 && !wv)
         return a.tshift ? launch_tw_ph_l<PH, CIK, true, 0, 2, false>(a, st) : launch_tw_ph_l<PH, CIK, false, 0, 2, false>(a, st);
     return a.tshift ? launch_tw_ph_l<PH, CIK, true, DBG, RDW>(a, st) : launch_tw_ph_l<PH, CIK, false, DBG, RDW>(a, st);
 }
-template <int PH, int CIK, bool LEFT, int DBG, int RDW, bool WVEC>
+template <int PH, int CIK, bool LEFT, int DBG, int RDW, bool WVEC, bool STATS>
 int launch_tw_ph_l(const TwArgs& a, hipStream_t st) {
     constexpr int NE = CIK * (PH == 0 ? 4 : 3) * 9 * 32;
     constexpr size_t smem = 2 * NE * sizeof(float);
@@ -493,7 +527,7 @@ int launch_tw_ph_l(const TwArgs& a, hipStream_t st) {
     if (b.ftiles == 0) return IDV_OK;
     const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.cotiles;
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
-    auto k = cconv_tw_kernel<PH, CIK, LEFT, DBG, RDW, WVEC>;
+    auto k = cconv_tw_kernel<PH, CIK, LEFT, DBG, RDW, WVEC, STATS>;
     if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return IDV_ELAUNCH;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), smem, st, b);
@@ -526,14 +560,17 @@ extern "C" int idv_pack_cconv_tw(const float* wino_frag, int Cout, int cin_used,
     return idv_launch_status();
 }
 
-// idv_cconv2d_wino_fwd (transposed = 1, no statistics, no addend) on the time-Winograd kernels: same result up to the rounding of
+// idv_cconv2d_wino_fwd (transposed = 1; statistics and addend as there) on the time-Winograd kernels: same result up to the rounding of
 // the transforms.  wfrag from idv_pack_cconv_tw, epi / has_fold from idv_pack_cconv_gauss.  Requires 16-byte aligned sources, Jp % 4
 // == 0 and, with a second source, the same pitch.  Reference: model/complex_progress.py:222-279 (+ :161-209 and pvae_module.py:82
 // for the epilogue).
 extern "C" int idv_ctconv2d_tw_fwd(const float* x0, int C0, const float* x1, int C1, const float* wfrag, const float* epi, int has_fold,
-                                   const float* prelu_slope, float* out, int tshift, int Cout, int Fin, int B, int Tp, int Jp,
-                                   int t_valid_out, void* stream) {
+                                   const float* prelu_slope, float* out, double* stats, double* stats_work, int stats_rep, int tshift,
+                                   int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, const float* addend, int addend_div,
+                                   int addend_Jp, void* stream) {
     if (!x0 || !wfrag || !epi || !out || C0 <= 0 || Cout <= 0 || Fin <= 0 || B <= 0 || Tp <= 1) return IDV_EINVAL;
+    if (stats && stats_work && (stats_rep < 2 || (stats_rep & (stats_rep - 1)))) return IDV_EINVAL;
+    if (addend && (addend_div < 1 || B % addend_div || addend_Jp < (B / addend_div) * Tp)) return IDV_EINVAL;
     if (C1 > 0 && !x1) return IDV_EINVAL;
     if (tshift != 0 && tshift != -1) return IDV_EINVAL;
     if (!idv_cconv_tw_supported(C0, C1, Cout, Fin)) return IDV_EINVAL;
@@ -548,21 +585,23 @@ extern "C" int idv_ctconv2d_tw_fwd(const float* x0, int C0, const float* x1, int
     a.epi = epi; a.has_fold = has_fold; a.slope = prelu_slope; a.out = out;
     a.Cout = Cout; a.cotiles = (Cout + 31) / 32;
     a.tshift = tshift; a.t_valid = t_valid_out;
+    a.add = addend; a.add_div = addend ? addend_div : 1; a.add_Jp = addend_Jp;
     if (Jp < a.J) return IDV_EINVAL;
     if ((long long)8 * Fin * (long long)Jp >= 0xffffffffLL) return IDV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    a.stats = stats;
+    if (stats && stats_work) { a.stats = stats_work; a.stats_rep = stats_rep; }       // replicated sums, folded afterwards (common.hpp)
     static const int dbg = [] { const char* e = getenv("IDV_TW_DBG"); return e ? atoi(e) : 0; }();
     static const int only = [] { const char* e = getenv("IDV_TW_ONLY"); return e ? atoi(e) : 0; }();      // 1 / 2: one phase only
-    if (dbg) {
-        int rc = 0;
+    int rc = 0;
+    if (dbg && !stats) {                                      // timing experiments (wrong results): DBG bits of the kernel
         if (only != 2) rc = dbg == 1 ? launch_tw_ph<0, 8, 1>(a, st) : (dbg == 2 ? launch_tw_ph<0, 8, 2>(a, st) : launch_tw_ph<0, 8, 3>(a, st));
         if (rc) return rc;
         if (only != 1) rc = dbg == 1 ? launch_tw_ph<1, 8, 1>(a, st) : (dbg == 2 ? launch_tw_ph<1, 8, 2>(a, st) : launch_tw_ph<1, 8, 3>(a, st));
         return rc;
     }
-    static const int rdw = [] { const char* e = getenv("IDV_TW_RDW"); return e ? atoi(e) : 2; }();      // (experiments) weight ring depth
-    if (only != 2)
-        if (int rc = (rdw == 4 ? launch_tw_ph<0, 8, 0, 4>(a, st) : launch_tw_ph<0, 8>(a, st))) return rc;
-    if (only == 1) return IDV_OK;
-    return rdw == 4 ? launch_tw_ph<1, 8, 0, 4>(a, st) : launch_tw_ph<1, 8>(a, st);
+    if (only != 2) rc = launch_tw_ph<0, 8>(a, st);
+    if (!rc && only != 1) rc = launch_tw_ph<1, 8>(a, st);
+    if (rc || !(stats && stats_work)) return rc;
+    return idv_launch_stats_collapse(stats_work, stats_rep, Cout * 5, stats, st);
 }

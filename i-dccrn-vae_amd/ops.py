@@ -283,7 +283,7 @@ def _pack_wino(w_re, w_im, cout: int, cin_total: int, cin_used: int, transposed:
 
 
 # ... and, for the transposed operators, with the TIME taps in Winograd form too (csrc/cgemm_tw.hip): 3 instead of 4 products per pair
-# of output columns.  Evaluation forward and data gradients (no statistics, no addend); IDV_TW=0 (or ops.TW = False before the weights
+# of output columns.  IDV_TW=0 (or ops.TW = False before the weights
 # are packed) keeps cgemm_wino.  Measured at B = 64: dec0-3 38.9 -> 35.2 ms, headline 823 -> 864 utt/s on the same box.
 TW = os.environ.get("IDV_TW", "1") != "0"
 TW_CFG = 5000000                 # LAUNCH_LOG ids of a launch on the time-Winograd kernels: TW_CFG (+ 1: taps (x[t-1], x[t]))
@@ -553,13 +553,15 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
             ev1.record()
             LAUNCH_LOG.append((cfg, macs, ev0, ev1))
         return out
-    if (transposed and skip_div == 1 and stats is None and addend is None
-            and _tw_ok(gauss, x, c1, cout, skip.Jp if skip is not None else None)):
+    if transposed and skip_div == 1 and _tw_ok(gauss, x, c1, cout, skip.Jp if skip is not None else None):
         # fp32: Winograd-transformed frequency and time taps (csrc/cgemm_tw.hip)
         if LAUNCH_LOG is not None:
             cfg = TW_CFG + (1 if tshift else 0)
+        swork = _stats_work(stats, cout)
         call("idv_ctconv2d_tw_fwd", x.ptr(), i(x.C), skip.ptr() if skip is not None else p(None), i(c1), p(gauss[4]), p(gauss[1]),
-             i(gauss[2]), p(slope), out.ptr(), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
+             i(gauss[2]), p(slope), out.ptr(), p(stats), p(swork), i(STATS_REP), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp),
+             i(t_out), addend.ptr() if addend is not None else p(None), i(addend_div), i(addend.Jp if addend is not None else 0),
+             stream_ptr())
     elif skip_div == 1 and _wino_ok(gauss, transposed, x, c1, cout, skip.Jp if skip is not None else None):
         # fp32: Winograd-transformed frequency taps on top of the three products (csrc/cgemm_wino.hip)
         if LAUNCH_LOG is not None:
@@ -1016,8 +1018,8 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
     if wfrag_bf16 is None and adj_transposed and _tw_ok(gauss, dy, 0, cout_adj, None):
         if LAUNCH_LOG is not None:
             cfg = TW_CFG + (1 if tshift_adj else 0)
-        call("idv_ctconv2d_tw_fwd", dy.ptr(), i(dy.C), p(None), i(0), p(gauss[4]), p(gauss[1]), i(0), p(None), out.ptr(),
-             i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), stream_ptr())
+        call("idv_ctconv2d_tw_fwd", dy.ptr(), i(dy.C), p(None), i(0), p(gauss[4]), p(gauss[1]), i(0), p(None), out.ptr(), p(None), p(None),
+             i(0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), p(None), i(1), i(0), stream_ptr())
     elif wfrag_bf16 is None and _wino_ok(gauss, adj_transposed, dy, 0, cout_adj, None):
         # the data gradient on the Winograd kernels (csrc/cgemm_wino.hip): adjoint of a conv = a transposed conv and vice versa
         if LAUNCH_LOG is not None:

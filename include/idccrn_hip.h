@@ -601,14 +601,15 @@ int idv_cconv2d_wino_fwd(const float* x0, int C0, const float* x1, int C1, const
  * taps in F(2,2) form over pairs of output columns: 3 instead of 4 real products per column pair and channel pair, i.e. 3/4 x 7/10
  * x 3/4 = 0.39 of the reference's real products.  Same result up to the rounding of the transforms.  idv_pack_cconv_tw re-orders
  * the fragments of idv_pack_cconv_wino(transposed = 1) (wino_frag) into idv_cconv_tw_wfrag_floats floats; epi / has_fold from
- * idv_pack_cconv_gauss.  No statistics, no addend (the evaluation forward and the data gradients).  Sources at pitch Jp
- * (Jp % 4 == 0, 16-byte aligned), C0 % 8 == 0 with a second source. */
+ * idv_pack_cconv_gauss; statistics and addend as idv_cconv2d_wino_fwd.  Sources at pitch Jp (Jp % 4 == 0, 16-byte aligned),
+ * C0 % 8 == 0 with a second source.  IDV_TW=0 (Python side) keeps idv_cconv2d_wino_fwd. */
 int idv_cconv_tw_supported(int C0, int C1, int Cout, int Fin);
 long long idv_cconv_tw_wfrag_floats(int Cout, int cin_used);
 int idv_pack_cconv_tw(const float* wino_frag, int Cout, int cin_used, float* tw_frag, void* stream);
 int idv_ctconv2d_tw_fwd(const float* x0, int C0, const float* x1, int C1, const float* wfrag, const float* epi, int has_fold,
-                        const float* prelu_slope, float* out, int tshift, int Cout, int Fin, int B, int Tp, int Jp,
-                        int t_valid_out, void* stream);
+                        const float* prelu_slope, float* out, double* stats, double* stats_work, int stats_rep, int tshift,
+                        int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, const float* addend, int addend_div,
+                        int addend_Jp, void* stream);
 
 #ifdef __cplusplus
 }
