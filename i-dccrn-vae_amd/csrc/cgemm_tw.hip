@@ -43,6 +43,7 @@ struct TwArgs {
     const float* add;     // optional addend (see cgemm_gauss.hip)
     int add_div, add_Jp;
     int jtiles, ftiles;
+    int xcd_split;        // block order: the co tiles of a column block on different XCDs (see the kernel)
 };
 
 constexpr int TW_PACK_CI = 8;      // pack granularity in complex input channels (cgemm_wino's WCIK)
@@ -100,10 +101,21 @@ __global__ __launch_bounds__(256, 2) void cconv_tw_kernel(const TwArgs a) {
     // they read the same raw input rows
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
-    const int per = a.cotiles * a.ftiles;
-    const int jt = (slot / per) * 8 + xcd;
-    const int rem = slot - (slot / per) * per;
-    const int ft = rem / a.cotiles, ct = rem - ft * a.cotiles;
+    int jt, ft, ct;
+    if (a.xcd_split) {
+        // 2 / 4 / 8 co tiles: co tile ct always on the XCDs = ct (mod cotiles), so that an XCD streams 1 / cotiles of the layer's taps
+        // (2 - 5 MB: its L2 holds them) and the raw rows of a column block are read by cotiles XCDs instead of one
+        const int G = 8 / a.cotiles;
+        ct = xcd % a.cotiles;
+        jt = (slot / a.ftiles) * G + xcd / a.cotiles;
+        ft = slot - (slot / a.ftiles) * a.ftiles;
+    } else {
+        const int per = a.cotiles * a.ftiles;
+        jt = (slot / per) * 8 + xcd;
+        const int rem = slot - (slot / per) * per;
+        ft = rem / a.cotiles;
+        ct = rem - ft * a.cotiles;
+    }
     if (jt >= a.jtiles) return;
     const int j0 = jt * 64;
     const int m0 = 2 * ft;
@@ -525,7 +537,14 @@ int launch_tw_ph_l(const TwArgs& a, hipStream_t st) {
     b.jtiles = (a.J + 63) / 64;
     b.ftiles = PH == 1 ? a.Fin / 2 : (a.Fin + 1) / 2;
     if (b.ftiles == 0) return IDV_OK;
-    const long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.cotiles;
+    // co tiles on different XCDs: dec0-3 at B = 64 34.7 -> 34.3 ms (dec0, eight co tiles: 9.81 -> 9.54); IDV_TW_XCD_SPLIT=0: one XCD per column block
+    static const int xsplit = [] { const char* e = getenv("IDV_TW_XCD_SPLIT"); return e ? atoi(e) : 1; }();
+    b.xcd_split = (xsplit && (b.cotiles == 2 || b.cotiles == 4 || b.cotiles == 8)) ? 1 : 0;
+    long long nblk = (long long)((b.jtiles + 7) / 8) * 8 * b.ftiles * b.cotiles;
+    if (b.xcd_split) {
+        const int G = 8 / b.cotiles;
+        nblk = (long long)((b.jtiles + G - 1) / G) * b.ftiles * 8;
+    }
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
     auto k = cconv_tw_kernel<PH, CIK, LEFT, DBG, RDW, WVEC, STATS>;
     if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
