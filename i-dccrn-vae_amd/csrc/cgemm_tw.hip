@@ -555,10 +555,14 @@ int launch_tw_ph_l(const TwArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// 1 if idv_ctconv2d_tw_fwd serves the layer: what cgemm_wino's transposed form serves, with C0 a multiple of 8 when there is a
-// second source (a K chunk of 8 channels never straddles the sources)
+// 1 if idv_ctconv2d_tw_fwd serves the layer: a transposed conv that cgemm_gauss serves, with at least two input rows, at least one
+// FULL tile of 32 complex output channels (a workgroup is one co tile x 64 columns, so unlike cgemm_wino's four-co-tile form the
+// 32-channel layer dec4 is served: 6.13 -> see DESIGN.md 3.1e) and, with a second source, C0 a multiple of 8 (a K chunk of 8 channels
+// never straddles the sources).  IDV_TW_MIN_COUT (experiments): narrowest output served.
 extern "C" int idv_cconv_tw_supported(int C0, int C1, int Cout, int Fin) {
-    if (!idv_cconv_wino_supported(1, C0, C1, Cout, Fin)) return 0;
+    static const int min_cout = [] { const char* e = getenv("IDV_TW_MIN_COUT"); return e ? atoi(e) : 32; }();
+    if (Cout < min_cout || Fin < 2) return 0;
+    if (!idv_cconv_gauss_supported(C0, C1, Cout)) return 0;
     return (C1 == 0 || C0 % 8 == 0) ? 1 : 0;
 }
 

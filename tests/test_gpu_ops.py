@@ -163,6 +163,7 @@ def test_cconv_wino(ops, transposed, causal, cin, cout, F, T, B, skip_c, fold, s
     (True, 32, 64, 33, 645, 2, 32, False, 0.25),    # utterance-length columns, Tp = 646, column tail
     (True, 256, 64, 17, 70, 2, 0, True, 0.25),      # a real layer width (dec3's channels)
     (True, 16, 36, 4, 31, 3, 4, False, None),       # J = 96: not a multiple of 64; second source of 4 channels (ragged last chunk)
+    (True, 16, 32, 9, 37, 2, 16, True, 0.25),       # ONE co tile (dec4's width: cgemm_wino does not serve it, cgemm_gauss is the reference)
 ])
 def test_ctconv_time_winograd(ops, causal, cin, cout, F, T, B, skip_c, fold, slope):
     """The transposed conv with Winograd-transformed frequency AND time taps (csrc/cgemm_tw.hip: F(2,2) over pairs of output
