@@ -286,17 +286,28 @@ def _pack_wino(w_re, w_im, cout: int, cin_total: int, cin_used: int, transposed:
 # of output columns.  IDV_TW=0 (or ops.TW = False before the weights
 # are packed) keeps cgemm_wino.  Measured at B = 64: dec0-3 38.9 -> 35.2 ms, headline 823 -> 864 utt/s on the same box.
 TW = os.environ.get("IDV_TW", "1") != "0"
-TW_CFG = 5000000                 # LAUNCH_LOG ids of a launch on the time-Winograd kernels: TW_CFG (+ 1: taps (x[t-1], x[t]))
+TW_CONV = os.environ.get("IDV_TW_CONV", "0") == "1"      # the conv form (csrc/cgemm_tw2.hip): opt-in while it is being measured
+TW_CFG = 5000000                 # LAUNCH_LOG ids of a launch on the time-Winograd kernels: TW_CFG (+ 1: taps (x[t-1], x[t]); + 2: the conv form)
 
 
 def _pack_wino_tw(w_re, w_im, cout: int, cin_total: int, cin_used: int, transposed: bool, conj: int):
-    """-> (wino fragments | None, time-Winograd fragments | None): the tail of a gauss pack tuple."""
+    """-> (wino fragments | None, time-Winograd fragments | None): the tail of a gauss pack tuple (the time-Winograd fragments are
+    those of the OPERATOR's form: csrc/cgemm_tw.hip for a transposed conv, csrc/cgemm_tw2.hip for a conv)."""
     wf = _pack_wino(w_re, w_im, cout, cin_total, cin_used, transposed, conj)
-    if wf is None or not (TW and transposed):
+    if wf is None or not TW or (not transposed and not TW_CONV):
         return wf, None
-    tw = torch.empty(int(_ll_fn("idv_cconv_tw_wfrag_floats")(i(cout), i(cin_used))), dtype=torch.float32, device=w_re.device)
-    call("idv_pack_cconv_tw", p(wf), i(cout), i(cin_used), p(tw), stream_ptr())
+    if transposed:
+        tw = torch.empty(int(_ll_fn("idv_cconv_tw_wfrag_floats")(i(cout), i(cin_used))), dtype=torch.float32, device=w_re.device)
+        call("idv_pack_cconv_tw", p(wf), i(cout), i(cin_used), p(tw), stream_ptr())
+    else:
+        tw = torch.empty(int(_ll_fn("idv_cconv_tw2_wfrag_floats")(i(cout), i(cin_used))), dtype=torch.float32, device=w_re.device)
+        call("idv_pack_cconv_tw2", p(wf), i(cout), i(cin_used), p(tw), stream_ptr())
     return wf, tw
+
+
+def _tw2_ok(gauss, x: Planar, c1: int, cout: int) -> bool:
+    return (gauss is not None and TW and TW_CONV and WINO and c1 == 0 and len(gauss) > 4 and gauss[4] is not None and x.Jp % 4 == 0
+            and bool(L.lib().idv_cconv_tw2_supported(i(x.C), i(cout), i(x.F))))
 
 
 def _tw_ok(gauss, x: Planar, c1: int, cout: int, skip_jp: Optional[int]) -> bool:
@@ -562,6 +573,13 @@ def cconv2d(x: Planar, wfrag, bias, cout: int, *, transposed=False, causal=True,
              i(gauss[2]), p(slope), out.ptr(), p(stats), p(swork), i(STATS_REP), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp),
              i(t_out), addend.ptr() if addend is not None else p(None), i(addend_div), i(addend.Jp if addend is not None else 0),
              stream_ptr())
+    elif not transposed and addend is None and _tw2_ok(gauss, x, c1, cout):
+        # fp32 conv: Winograd-transformed frequency and time taps (csrc/cgemm_tw2.hip)
+        if LAUNCH_LOG is not None:
+            cfg = TW_CFG + 2 + (1 if tshift else 0)
+        swork = _stats_work(stats, cout)
+        call("idv_cconv2d_tw_fwd", x.ptr(), i(x.C), p(gauss[4]), p(gauss[1]), i(gauss[2]), p(slope), out.ptr(), p(stats), p(swork),
+             i(STATS_REP), i(tshift), i(cout), i(x.F), i(x.B), i(x.Tp), i(x.Jp), i(t_out), stream_ptr())
     elif skip_div == 1 and _wino_ok(gauss, transposed, x, c1, cout, skip.Jp if skip is not None else None):
         # fp32: Winograd-transformed frequency taps on top of the three products (csrc/cgemm_wino.hip)
         if LAUNCH_LOG is not None:
@@ -1020,6 +1038,11 @@ def cconv_dgrad(dy: Planar, wfrag, bias, cout_adj: int, fwd_transposed: bool, ca
             cfg = TW_CFG + (1 if tshift_adj else 0)
         call("idv_ctconv2d_tw_fwd", dy.ptr(), i(dy.C), p(None), i(0), p(gauss[4]), p(gauss[1]), i(0), p(None), out.ptr(), p(None), p(None),
              i(0), i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), p(None), i(1), i(0), stream_ptr())
+    elif wfrag_bf16 is None and not adj_transposed and _tw2_ok(gauss, dy, 0, cout_adj):
+        if LAUNCH_LOG is not None:
+            cfg = TW_CFG + 2 + (1 if tshift_adj else 0)
+        call("idv_cconv2d_tw_fwd", dy.ptr(), i(dy.C), p(gauss[4]), p(gauss[1]), i(0), p(None), out.ptr(), p(None), p(None), i(0),
+             i(tshift_adj), i(cout_adj), i(dy.F), i(dy.B), i(dy.Tp), i(dy.Jp), i(t_out), stream_ptr())
     elif wfrag_bf16 is None and _wino_ok(gauss, adj_transposed, dy, 0, cout_adj, None):
         # the data gradient on the Winograd kernels (csrc/cgemm_wino.hip): adjoint of a conv = a transposed conv and vice versa
         if LAUNCH_LOG is not None:

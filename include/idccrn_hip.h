@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IDV_ABI_VERSION 8
+#define IDV_ABI_VERSION 9
 #define IDV_SLACK_FLOATS 256
 
 int idv_abi_version(void);
@@ -610,6 +610,18 @@ int idv_ctconv2d_tw_fwd(const float* x0, int C0, const float* x1, int C1, const 
                         const float* prelu_slope, float* out, double* stats, double* stats_work, int stats_rep, int tshift,
                         int Cout, int Fin, int B, int Tp, int Jp, int t_valid_out, const float* addend, int addend_div,
                         int addend_Jp, void* stream);
+
+/* ---- conv with Winograd-transformed frequency AND time taps (cgemm_tw2.hip) ---------------------------------------------------
+ * The encoder block's contraction (model/complex_progress.py:8-36) as idv_cconv2d_wino_fwd(transposed = 0) with the two time taps
+ * in F(2,2) form (0.39 of the reference's real products); one source, no addend.  idv_pack_cconv_tw2 re-orders the fragments of
+ * idv_pack_cconv_wino(transposed = 0) into idv_cconv_tw2_wfrag_floats floats; epi / has_fold from idv_pack_cconv_gauss;
+ * statistics as idv_cconv2d_wino_fwd.  Source at pitch Jp (Jp % 4 == 0, 16-byte aligned). */
+int idv_cconv_tw2_supported(int Cin, int Cout, int Fin);
+long long idv_cconv_tw2_wfrag_floats(int Cout, int cin_used);
+int idv_pack_cconv_tw2(const float* wino_frag, int Cout, int cin_used, float* tw_frag, void* stream);
+int idv_cconv2d_tw_fwd(const float* x0, int Cin, const float* wfrag, const float* epi, int has_fold, const float* prelu_slope,
+                       float* out, double* stats, double* stats_work, int stats_rep, int tshift, int Cout, int Fin, int B, int Tp,
+                       int Jp, int t_valid_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -186,6 +186,37 @@ def test_ctconv_time_winograd(ops, causal, cin, cout, F, T, B, skip_c, fold, slo
     assert e < 5e-6
 
 
+@pytest.mark.parametrize("causal,cin,cout,F,T,B,fold,slope", [
+    (True, 32, 64, 129, 70, 2, False, None),        # two co tiles, odd output row count (65): a half tile
+    (True, 8, 40, 65, 33, 2, True, 0.2),            # ragged second co tile, fold + PReLU
+    (True, 72, 128, 17, 40, 3, False, None),        # four co tiles, 72 input channels
+    (True, 11, 36, 9, 21, 2, False, 0.1),           # odd channel count (ragged last K chunk), 5 output rows
+    (False, 12, 40, 17, 9, 2, False, None),         # non-causal taps (x[t], x[t+1])
+    (True, 8, 48, 5, 700, 1, False, None),          # many column tiles, 3 output rows, odd Tp
+    (True, 128, 128, 33, 70, 2, True, 0.25),        # a real layer width (enc3)
+    (True, 16, 32, 4, 30, 3, True, None),           # even input row count (Fout = 2: one tile), one co tile
+])
+def test_cconv_time_winograd(ops, causal, cin, cout, F, T, B, fold, slope):
+    """The conv with Winograd-transformed frequency AND time taps (csrc/cgemm_tw2.hip) against the oracle's four real convolutions and
+    against the kernel it replaces (cgemm_wino's conv form or cgemm_gauss)."""
+    keep = ops.WINO, ops.TW, ops.TW_CONV, ops.LAUNCH_LOG
+    assert ops.L.lib().idv_cconv_tw2_supported(cin, cout, F)
+    try:
+        ops.WINO = ops.TW = ops.TW_CONV = True
+        ops.LAUNCH_LOG = []
+        got = _conv_case(ops, causal, False, cin, cout, F, T, B, seed=67, fold=fold, slope=slope, gauss=True)
+        assert [c for c, *_ in ops.LAUNCH_LOG if c in (ops.TW_CFG + 2, ops.TW_CFG + 3)], "time-Winograd conv kernel not launched"
+        ops.TW_CONV = False
+        ops.LAUNCH_LOG = []
+        ref = _conv_case(ops, causal, False, cin, cout, F, T, B, seed=67, fold=fold, slope=slope, gauss=True)
+        assert not [c for c, *_ in ops.LAUNCH_LOG if c in (ops.TW_CFG + 2, ops.TW_CFG + 3)]
+    finally:
+        ops.WINO, ops.TW, ops.TW_CONV, ops.LAUNCH_LOG = keep
+    e = relerr(got, ref)
+    print(f"time-Winograd conv vs the kernel it replaces: {e:.2e}")
+    assert e < 5e-6
+
+
 def test_ctconv_time_winograd_adjoint(ops):
     """The data gradient of a conv (= a transposed conv with conjugate-transposed weights, reversed time taps) on the
     time-Winograd kernels against cgemm_wino."""

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(amd):
     lib = L.lib()                                    # raises if the .so is missing or a symbol is absent
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.idv_abi_version() == 8          # 2: backward entry points; 3: split-image hand-over inside idv_clstm_fwd; 4: IDV_ECOOP status; 5: idv_cconv_gauss_config takes Cin, idv_lstm_stack2_f32 / idv_clstm_fwd2; 6: idv_bucket_*; 7: idv_cconv_wino_*; 8: idv_cconv_tw_* / idv_ctconv2d_tw_fwd
+    assert lib.idv_abi_version() == 9          # 2: backward entry points; 3: split-image hand-over inside idv_clstm_fwd; 4: IDV_ECOOP status; 5: idv_cconv_gauss_config takes Cin, idv_lstm_stack2_f32 / idv_clstm_fwd2; 6: idv_bucket_*; 7: idv_cconv_wino_*; 8: idv_cconv_tw_* / idv_ctconv2d_tw_fwd; 9: idv_cconv_tw2_* / idv_cconv2d_tw_fwd
     assert lib.idv_cconv_cck(ctypes.c_int(1)) == 2 and lib.idv_cconv_cck(ctypes.c_int(32)) == 4
     assert lib.idv_cconv_config(ctypes.c_int(1), ctypes.c_int(64), ctypes.c_int(1), ctypes.c_int(129)) == 1000001          # the one-output-channel vector-ALU kernel
     lib.idv_clstm_work_floats.restype = ctypes.c_longlong
