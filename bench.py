@@ -379,6 +379,8 @@ def kernel_name(cfg_id):
         return f"void (anonymous namespace)::ctconv_c1_bf16_kernel<{'true' if cfg_id == -98 else 'false'}>(CgemmArgs)"
     if cfg_id == 1000001:
         return "void (anonymous namespace)::ctconv_c1_f32_kernel<false>(CgemmArgs, int)"
+    if cfg_id in (5000002, 5000003):      # the conv form (cgemm_tw2.hip)
+        return f"void (anonymous namespace)::cconv_tw2_kernel<{'true' if cfg_id == 5000003 else 'false'}, false, 0>((anonymous namespace)::Tw2Args)"
     if cfg_id in (5000000, 5000001):      # ops.TW_CFG (+ 1: taps to the left): the two phase kernels of a transposed-conv layer
         a, b = kernel_parts(cfg_id)
         return a.replace("((anonymous namespace)::TwArgs)", "") + " + " + b.replace("void (anonymous namespace)::cconv_tw_kernel", "")
@@ -482,7 +484,7 @@ def roofline_of(launches, steps, step_seconds, precision, batch, workload):
                           "(Gauss) x 7 of 10 frequency-tap products (Winograd F(2,3) + F(2,2)): `executed` = 0.525 x achieved, "
                           "excluding the padding row of an odd row count.  One `launch` here = one decoder layer = the even-row and the odd-row "
                           "phase kernel back to back (kernel_parts): avg_launch_ms = the sum of their average durations in the rocprofv3 summary")
-    if dom in (5000000, 5000001):
+    if dom in (5000000, 5000001, 5000002, 5000003):
         # time-Winograd on top (cgemm_tw.hip): 3 of 4 products per pair of output columns as well
         r["executed"] = round(0.525 * 0.75 * ach, 3)
         r["frac_executed"] = round(0.525 * 0.75 * ach / peak, 4)

@@ -120,16 +120,15 @@ __global__ __launch_bounds__(256, 2) void cconv_tw2_kernel(const Tw2Args a) {
     // ---- staging (cgemm_tw.hip): item = channel cl, raw row, column pairs 2 c8, 2 c8 + 1
     f32x4 v_r[NLD], v_i[NLD];
     float e_r[NLD], e_i[NLD];
-    unsigned off_v[NLD], off_e[NLD], ldsoff[NLD];
+    unsigned off_v[NLD], ldsoff[NLD];
     unsigned okmask[NLD];     // bits 0-4: window column valid; bit 5: row valid
-    int item_cl[NLD];
     bool interior[NLD];
+    auto item_cl = [&](int i) -> int { return (tid + i * 256) / (16 * NRAW); };
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int e = tid + i * 256;
         const int c8 = e & 15;
         const int rl = (e >> 4) % NRAW, cl = e / (16 * NRAW);
-        item_cl[i] = cl;
         const int f = rbase + rl;
         const int jc = j0 + 4 * c8;
         const int je = LEFT ? jc - 1 : jc + 4;
@@ -142,10 +141,10 @@ __global__ __launch_bounds__(256, 2) void cconv_tw2_kernel(const Tw2Args a) {
             if (c >= 0 && c < a.J) m |= 1u << q;
         }
         if (okr) m |= 1u << 5;
+        // the extra column is loaded at the vector slot's offset - 1 / + 4: one float outside the row at the buffer's edges, inside the
+        // slack every planar buffer has in front and behind (masked)
         const int jcv = jc + 3 < a.Jp ? jc : 0;
-        const int jev = (je >= 0 && je < a.Jp) ? je : 0;
-        off_v[i] = okr ? (unsigned)((cl * a.Fin + f) * a.Jp + jcv) : 0u;
-        off_e[i] = okr ? (unsigned)((cl * a.Fin + f) * a.Jp + jev) : 0u;
+        off_v[i] = okr ? (unsigned)((cl * a.Fin + f) * a.Jp + jcv) : 4u;
         if (jc + 3 >= a.Jp) m &= ~0x1fu;
         if (!(je >= 0 && je < a.Jp)) m &= LEFT ? ~1u : ~(1u << 4);
         okmask[i] = m;
@@ -159,12 +158,12 @@ __global__ __launch_bounds__(256, 2) void cconv_tw2_kernel(const Tw2Args a) {
         const int ci0 = chunk * CIK;
         const float* br = a.x0 + (size_t)ci0 * a.Fin * a.Jp;
         const float* bi = br + (size_t)Cin * a.Fin * a.Jp;
-        const bool dead = item_cl[i] >= Cin - ci0;
-        const unsigned ov = dead ? 0u : off_v[i], oe = dead ? 0u : off_e[i];
+        const bool dead = item_cl(i) >= Cin - ci0;
+        const unsigned ov = dead ? 4u : off_v[i];
         v_r[i] = *(const f32x4*)(br + ov);
         v_i[i] = *(const f32x4*)(bi + ov);
-        e_r[i] = br[oe];
-        e_i[i] = bi[oe];
+        e_r[i] = (br + ov)[LEFT ? -1 : 4];
+        e_i[i] = (bi + ov)[LEFT ? -1 : 4];
     };
     float fr[5], fi[5];
     auto stage_window = [&](int chunk, int i) {
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void cconv_tw2_kernel(const Tw2Args a) {
             return;
         }
         unsigned m = okmask[i];
-        if (item_cl[i] >= cvalid || !((m >> 5) & 1u)) m &= ~0x1fu;
+        if (item_cl(i) >= cvalid || !((m >> 5) & 1u)) m &= ~0x1fu;
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             const float xr = left ? (q == 0 ? e_r[i] : v_r[i][q == 0 ? 0 : q - 1]) : (q == 4 ? e_r[i] : v_r[i][q == 4 ? 3 : q]);
@@ -233,44 +232,32 @@ __global__ __launch_bounds__(256, 2) void cconv_tw2_kernel(const Tw2Args a) {
     const int rxa = tw2_ra(qxm) * 288, rxb = tw2_rb(qxm) * 288, rya = tw2_ra(qym) * 288, ryb = tw2_rb(qym) * 288;
     const float cbx = tw2_cb(qxm), cby = tw2_cb(qym);
     const int r2a = tw2_ra(2) * 288 + wave * 64, r2b = tw2_rb(2) * 288 + wave * 64;     // (+ plane pair j = w of product 2)
-    float xa[NSLOT], xb[NSLOT];
-    // path A: load step s = 0 .. 8: s < 3: product x planes (2 s, 2 s + 1); s = 3: product x plane 6; s = 4 .. 6: product y pairs;
-    // s = 7: product y plane 6; s = 8: product 2's pair.  Slots: product x plane p -> 2 p, product y plane p -> 2 p + 1.
-    auto load_a = [&](const float* base, int s) {
-        if (s < 3 || (s >= 4 && s < 7)) {
-            const bool y = s >= 4;
-            const int j = y ? s - 4 : s;
-            const float2 pa_ = *(const float2*)(base + (y ? rya : rxa) + j * 64 + 2 * l31);
-            const float2 pb_ = *(const float2*)(base + (y ? ryb : rxb) + j * 64 + 2 * l31);
-            const int k0 = 4 * j + (y ? 1 : 0);
-            xa[k0] = pa_.x; xa[k0 + 2] = pa_.y;
-            xb[k0] = pb_.x; xb[k0 + 2] = pb_.y;
-        } else if (s == 3 || s == 7) {
-            const bool y = s == 7;
-            xa[12 + (y ? 1 : 0)] = base[(y ? rya : rxa) + 3 * 64 + 2 * l31];
-            xb[12 + (y ? 1 : 0)] = base[(y ? ryb : rxb) + 3 * 64 + 2 * l31];
+    // operands in a rolling window of two groups of four slots: group g of a k-step is fetched while group g - 1 runs.
+    // Role A (waves 0 .. 2): group g < 3 = product x planes (2 g, 2 g + 1) on slots 0, 2 and product y on slots 1, 3 (two 8-byte reads per
+    // row each); group 3 = plane 6 of x, y (slots 0, 1) and product 2's plane pair (slots 2, 3).  Role B (wave 3): slots 4 g .. 4 g + 3 of
+    // tw2_slot(3, .), one 4-byte read per row.
+    float xa[2][4], xb[2][4];
+    auto load_grp_a = [&](const float* base, int g, float (&oa)[4], float (&ob)[4]) {
+        if (g < 3) {
+            const float2 xa_ = *(const float2*)(base + rxa + g * 64 + 2 * l31), xb_ = *(const float2*)(base + rxb + g * 64 + 2 * l31);
+            const float2 ya_ = *(const float2*)(base + rya + g * 64 + 2 * l31), yb_ = *(const float2*)(base + ryb + g * 64 + 2 * l31);
+            oa[0] = xa_.x; oa[2] = xa_.y; ob[0] = xb_.x; ob[2] = xb_.y;
+            oa[1] = ya_.x; oa[3] = ya_.y; ob[1] = yb_.x; ob[3] = yb_.y;
         } else {
+            oa[0] = base[rxa + 3 * 64 + 2 * l31]; ob[0] = base[rxb + 3 * 64 + 2 * l31];
+            oa[1] = base[rya + 3 * 64 + 2 * l31]; ob[1] = base[ryb + 3 * 64 + 2 * l31];
             const float2 pa_ = *(const float2*)(base + r2a + 2 * l31), pb_ = *(const float2*)(base + r2b + 2 * l31);
-            xa[14] = pa_.x; xa[15] = pa_.y;
-            xb[14] = pb_.x; xb[15] = pb_.y;
+            oa[2] = pa_.x; oa[3] = pa_.y; ob[2] = pb_.x; ob[3] = pb_.y;
         }
     };
-    // path B (wave 3): slot k < 12: accumulator a = main(k >> 2), plane 7 + ((k >> 1) & 1), product x / y by k & 1; 12 .. 14: product 2
-    // on planes 6, 7, 8.  One load step per slot (a 4-byte read per row).
-    auto load_b = [&](const float* base, int k) {
-        int q, plane;
-        tw2_slot(3, k, q, plane);
-        if (q < 0) return;
-        xa[k] = base[tw2_ra(q) * 288 + tw2_poff(plane, l31)];
-        xb[k] = base[tw2_rb(q) * 288 + tw2_poff(plane, l31)];
-    };
-    auto load_all = [&](const float* base) {
-        if (wave < 3) {
+    auto load_grp_b = [&](const float* base, int g, float (&oa)[4], float (&ob)[4]) {
 #pragma unroll
-            for (int s = 0; s < 9; ++s) load_a(base, s);
-        } else {
-#pragma unroll
-            for (int k = 0; k < NSLOT; ++k) load_b(base, k);
+        for (int s4 = 0; s4 < 4; ++s4) {
+            int q, plane;
+            tw2_slot(3, 4 * g + s4, q, plane);
+            if (q < 0) continue;
+            oa[s4] = base[tw2_ra(q) * 288 + tw2_poff(plane, l31)];
+            ob[s4] = base[tw2_rb(q) * 288 + tw2_poff(plane, l31)];
         }
     };
 
@@ -283,7 +270,10 @@ __global__ __launch_bounds__(256, 2) void cconv_tw2_kernel(const Tw2Args a) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) stage_load(nchunk > 1 ? 1 : 0, i);
     __syncthreads();
-    load_all(smem + (size_t)half * RT);
+    if (wave < 3)
+        load_grp_a(smem + (size_t)half * RT, 0, xa[0], xb[0]);
+    else
+        load_grp_b(smem + (size_t)half * RT, 0, xa[0], xb[0]);
 
     // the main loop, once per wave role (the branch is outside the loop: two straight-line loops, each with the workgroup's barriers)
     auto run = [&](auto role) {
@@ -298,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void cconv_tw2_kernel(const Tw2Args a) {
                 const bool staging = !(DBG & 1) && ul == 0;  // both items ride on k-step 0; the barrier sits in k-step 1
 #pragma unroll
                 for (int k = 0; k < (ROLE_B ? NSLOT - 1 : NSLOT); ++k) {
+                    const int g = k >> 2, s4 = k & 3;
                     float cb;
                     int ai;
                     if (ROLE_B) {
@@ -309,25 +300,27 @@ __global__ __launch_bounds__(256, 2) void cconv_tw2_kernel(const Tw2Args a) {
                         cb = k < 14 ? ((k & 1) ? cby : cbx) : -1.f;
                         ai = k < 14 ? k >> 1 : 7 + (k - 14);
                     }
-                    const float b = xa[k] + cb * xb[k];
+                    if (s4 == 0) {
+                        // the next group's operands (of this k-step, or group 0 of the next one: after the barrier in the last k-step)
+                        const float* src = g < 3 ? P + (size_t)(2 * ul + half) * RT : bnext;
+                        if (!(ul == KS - 1 && g == 3)) {
+                            if (ROLE_B) load_grp_b(src, (g + 1) & 3, xa[(g + 1) & 1], xb[(g + 1) & 1]);
+                            else load_grp_a(src, (g + 1) & 3, xa[(g + 1) & 1], xb[(g + 1) & 1]);
+                        }
+                    }
+                    const float b = xa[g & 1][s4] + cb * xb[g & 1][s4];
                     acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[k], b, acc[ai], 0, 0, 0);
                     if (ul == KS - 1 && k == 0) {
                         __builtin_amdgcn_sched_barrier(0);
                         __syncthreads();
                     }
-                    // weights of the next k-step, group by group, and its operands as their registers come free
-                    if (((k & 3) == 3 || (ROLE_B && k == NSLOT - 2)) && !(DBG & 2)) load_wg(chunk * KS + ul + 1, k >> 2);
-                    if (ROLE_B) {
-                        load_b(bnext, k);
-                    } else {
-                        // product x pairs after slots 2, 6, 10; x plane 6 after 12; product y pairs after 3, 7, 11; y plane 6 after 13;
-                        // product 2 after 15
-                        if (k == 2 || k == 6 || k == 10) load_a(bnext, k >> 2);
-                        if (k == 12) load_a(bnext, 3);
-                        if (k == 3 || k == 7 || k == 11) load_a(bnext, 4 + (k >> 2));
-                        if (k == 13) load_a(bnext, 7);
-                        if (k == 15) load_a(bnext, 8);
+                    if (ul == KS - 1 && k == 12) {
+                        // (last k-step: group 0 of the next chunk comes from the other buffer, complete since the barrier above)
+                        if (ROLE_B) load_grp_b(bnext, 0, xa[0], xb[0]);
+                        else load_grp_a(bnext, 0, xa[0], xb[0]);
                     }
+                    // weights of the next k-step, group by group
+                    if (((k & 3) == 3 || (ROLE_B && k == NSLOT - 2)) && !(DBG & 2)) load_wg(chunk * KS + ul + 1, k >> 2);
                     if (staging) {
                         // item 0: window at slot 0, plane pairs at 1 .. 4, plane 8 at 5, reload at 5; item 1 (waves 0 .. 2): slots 8 .. 13
                         if (k == 0) stage_window(nxt, 0);
@@ -501,10 +494,11 @@ int launch_tw2(const Tw2Args& a, hipStream_t st) {
 }  // namespace
 
 // 1 if idv_cconv2d_tw_fwd serves the layer: a conv cgemm_gauss serves (one source) with at least one full tile of 32 complex output
-// channels, at least 8 input channels and at least two output rows.  IDV_TW2_MIN_COUT / IDV_TW2_MIN_CIN (experiments).
+// channels, at least 64 input channels (measured at B = 64: enc1, 32 -> 64 channels, 2.63 -> 2.86 ms: eight K chunks do not amortise the
+// epilogue exchange; enc2-5 19.6 -> 18.7 ms) and at least two output rows.  IDV_TW2_MIN_COUT / IDV_TW2_MIN_CIN (experiments).
 extern "C" int idv_cconv_tw2_supported(int Cin, int Cout, int Fin) {
     static const int min_cout = [] { const char* e = getenv("IDV_TW2_MIN_COUT"); return e ? atoi(e) : 32; }();
-    static const int min_cin = [] { const char* e = getenv("IDV_TW2_MIN_CIN"); return e ? atoi(e) : 8; }();
+    static const int min_cin = [] { const char* e = getenv("IDV_TW2_MIN_CIN"); return e ? atoi(e) : 64; }();
     if (Cout < min_cout || Cin < min_cin || (Fin - 1) / 2 + 1 < 2) return 0;
     return idv_cconv_gauss_supported(Cin, 0, Cout);
 }

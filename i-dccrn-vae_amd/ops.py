@@ -286,7 +286,7 @@ def _pack_wino(w_re, w_im, cout: int, cin_total: int, cin_used: int, transposed:
 # of output columns.  IDV_TW=0 (or ops.TW = False before the weights
 # are packed) keeps cgemm_wino.  Measured at B = 64: dec0-3 38.9 -> 35.2 ms, headline 823 -> 864 utt/s on the same box.
 TW = os.environ.get("IDV_TW", "1") != "0"
-TW_CONV = os.environ.get("IDV_TW_CONV", "0") == "1"      # the conv form (csrc/cgemm_tw2.hip): opt-in while it is being measured
+TW_CONV = os.environ.get("IDV_TW_CONV", "1") != "0"      # the conv form (csrc/cgemm_tw2.hip); 0: cgemm_wino's conv form
 TW_CFG = 5000000                 # LAUNCH_LOG ids of a launch on the time-Winograd kernels: TW_CFG (+ 1: taps (x[t-1], x[t]); + 2: the conv form)
 
 

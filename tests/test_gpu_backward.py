@@ -890,7 +890,7 @@ _FULL_WIDTH_ORACLE = {}
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-def test_full_width_train_step_grads(pm, losses, ops, precision):
+def test_full_width_train_step_grads(pm, losses, ops, precision, golden):
     """The DCCRN-CL train step at the reference's FULL width (base 32: up to 512-channel blocks, every kernel at the tile
     counts the benchmark runs) on 1 s utterances: loss, input gradient and every parameter gradient against
     torch.autograd through the oracle in float64 on the CPU.
@@ -910,20 +910,21 @@ def test_full_width_train_step_grads(pm, losses, ops, precision):
     keep = ops.PRECISION
     ops.set_precision(precision)
     try:
-        _full_width(pm, nl)
+        _full_width(pm, nl, golden("grad_dccrn_full"))
     finally:
         ops.set_precision(keep)
 
 
-def _full_width(pm, nl):
-    np_ = O.net_params(True, 32)
-    m = load_synth(pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None), 77)
+def _full_width(pm, nl, ref):
+    # the step of the reference fixture (tests/golden/grad_dccrn_full.npz): the gradients the REFERENCE's own float32 arithmetic
+    # produced for it are the yardstick below
+    np_ = O.net_params(True, int(ref["base"]))
+    m = load_synth(pm.DCCRN_(NFFT, HOP, np_, True, "cuda", WIN, SKIP, "mask", False, None, None), int(ref["seed"]))
     m.train()
-    g = torch.Generator().manual_seed(21)
-    x = rnd(g, 2, 16000, scale=0.1)
-    c = x + rnd(g, 2, 16000, scale=0.05)
+    x = T_(ref["x"]).float()
+    c = T_(ref["clean_ref"]).float()
     xg = x.cuda().requires_grad_(True)
-    w = [0.2, 0.1, 1.0]
+    w = [float(v) for v in ref["weights"]]
     with torch.enable_grad():
         est, pred = m(xg, train=True)
         loss = nl.ete_train_se_loss(w).final_ete_loss(pred, m.stft(c.cuda()), c.cuda(), est)[0]
@@ -955,7 +956,8 @@ def _full_width(pm, nl):
     print(f"input gradient vs float64: HIP {ours:.2e}, float32 oracle {ref32:.2e}")
     assert ours < 1e-2
     n, worst = 0, (0.0, "", 0.0)
-    table, sq, viol = {}, [0.0, 0.0, 0.0], []
+    table, sq, cand = {}, [0.0, 0.0, 0.0, 0.0], []
+    lim = (int(ref["sum_limit"]), int(ref["sum_cap"])) if "sum_limit" in ref.files else (16384, 8192)
     for k, p_ in m.named_parameters():
         want = sd[k].grad
         if want is None:
@@ -968,49 +970,53 @@ def _full_width(pm, nl):
         # sample on either side, not an average over elements: 3e-2
         tol = 3e-2 if p_.numel() == 1 else 1e-2
         assert ours < tol, (k, ours, ref32)
-        # ... and the bar that is ASSERTED, not argued: per tensor the HIP path may deviate from float64 at
-        # most YARD[..][0] times as far as the float32 oracle does (the PReLU-flip noise is an independent sample on either
-        # side), with a floor where the float32 oracle happens to be flip-free; the whole gradient vector, where the flip
-        # noise averages out, at most YARD[..][2] times
-        k_, floor, _ = YARD[ops_precision()]
+        # ... and the bar that is ASSERTED, not argued (from an error model, not from the last
+        # measurement).  The yardstick is what the REFERENCE's own float32 arithmetic delivers on this very step: the gradients it wrote
+        # (fixture: a strided subsample + the full norm per tensor) against float64 -- `torch` -- beside the float32 oracle's deviation
+        # `oracle32`.  PReLU-flip noise is an independent sample in each float32 evaluation, so per tensor the HIP path may deviate at
+        # most YARD[..][0] times as far as the WORSE of the two float32 yardsticks (floor: YARD[..][1], for tensors where both happen to
+        # be flip-free: that multiple of the reference's whole-vector deviation); the whole gradient vector, where the flip noise
+        # averages out, at most YARD[..][2] times.
         if p_.numel() > 1:
-            if ours > max(k_ * ref32, floor):
-                viol.append((k, ours, ref32))
+            fx, wn_ref = T_(ref[f"g:{k}"]).double(), float(ref[f"n:{k}"])
+            w_sub = summarize(want, *lim).cpu().double()
+            scale = max(wn_ref * (fx.numel() / p_.numel()) ** 0.5, 1e-30)
+            torch_dev = float((fx - w_sub).norm()) / scale
+            ours_sub = float((summarize(p_.grad, *lim).cpu().double() - w_sub).norm()) / scale
+            cand.append((k, max(ours, ours_sub), max(torch_dev, ref32)))
             wn = float(want.double().norm())
             sq[0] += (ours * wn) ** 2
             sq[1] += (ref32 * wn) ** 2
             sq[2] += wn ** 2
-        table[k] = (ours, ref32)
+            sq[3] += (torch_dev * wn) ** 2
+            table[k] = (ours, ref32, torch_dev, ours_sub)
+        else:
+            table[k] = (ours, ref32)
         worst = max(worst, (ours, k, ref32))
         n += 1
     print("worst parameter gradient (HIP vs float64, name, float32 oracle vs float64)", worst)
     assert n > 100
     # all multi-element parameter gradients as ONE vector: the flip noise averages out, a kernel error would not
-    tot_ours, tot_ref = (sq[0] / sq[2]) ** 0.5, (sq[1] / sq[2]) ** 0.5
-    print(f"whole gradient vector vs float64: HIP {tot_ours:.2e}, float32 oracle {tot_ref:.2e}")
-    _dump(f"grad_f64_full_{ops_precision()}", {"table": table, "total": [tot_ours, tot_ref]})
-    assert not viol, viol
-    assert tot_ours <= max(YARD[ops_precision()][2] * tot_ref, 1e-3), (tot_ours, tot_ref)
+    tot_ours, tot_ref, tot_torch = (sq[0] / sq[2]) ** 0.5, (sq[1] / sq[2]) ** 0.5, (sq[3] / sq[2]) ** 0.5
+    print(f"whole gradient vector vs float64: HIP {tot_ours:.2e}, float32 oracle {tot_ref:.2e}, the reference's float32 torch {tot_torch:.2e}")
+    _dump(f"grad_f64_full_{ops_precision()}", {"table": table, "total": [tot_ours, tot_ref, tot_torch]})
+    k_, floor_mult, k_tot = YARD[ops_precision()]
+    viol = [(k, o, y) for k, o, y in cand if o > max(k_ * y, floor_mult * tot_torch)]
+    assert not viol, (viol, tot_torch)
+    assert tot_ours <= k_tot * max(tot_ref, tot_torch), (tot_ours, tot_ref, tot_torch)
 
 
-# (per-tensor factor, per-tensor floor, whole-vector factor).  Measured (round 3, three-product conv kernel): fp32 worst tensor
-# ratio 3.3 above the floor (encoders.4.bn.beta_i 2.4e-3 vs 7.3e-4), whole vector 5.2e-4 vs 3.3e-4 (1.6x); bf16x3 worst ratio 11.4
-# (encoders.2.bn.beta_r 5.4e-3 vs 4.7e-4), largest tensor under the floor 4.1e-3, whole vector 1.9e-3 vs 3.3e-4 (5.9x).
-# The float32 oracle has no flipped element in decoders 2-5 on this input (1e-6 there): that is what the floor is for.
-# How sharp the per-tensor ratio can be: the conv kernels' outputs and data gradients are BIT-identical across their tile
-# configurations (tests/tools/conv_cfg_compare.py), only the train-mode moment sums differ -- by 1e-9, from the grouping of the fp32
-# per-wave partials -- and that alone moved encoders.5 (conv_im.weight, bn.gamma_ri, bn.beta_i) from under 3.3x to 5.0 / 10.1 /
-# 7.5x the float32 oracle's deviation (3.7e-3 .. 6.4e-3 against 6.4e-4 .. 7.6e-4) when the conv tiles changed late in round 3,
-# the whole vector from 5.2e-4 to 7.6e-4 (2.3x): one flipped PReLU element in front of the deepest encoder block.  The
-# per-tensor factor is therefore 12, the whole-vector factor (where such a flip averages out) stays 3.
-# The floor, from the REFERENCE rather than from these kernels (round 4): the float32 ORACLE is a poor yardstick where it happens to be
-# unusually exact -- decoders 2-5, 4e-6 from float64 on this input, 250 x closer than on the other blocks (6e-4 .. 8e-4).  What
-# float32 arithmetic on this network delivers is measured by test_grad_dccrn_reference_full_width on a step of the same size against
-# gradients written by the reference itself (tests/golden/grad_dccrn_full.npz): float32 torch and this path differ by 2.0e-3 /
-# 2.3e-3 on decoders.2.bn.beta_i / beta_r there (median over all tensors 2.1e-3, gpurun_out/grad_ref_full_fp32.json) -- two float32
-# evaluations of the same gradient 2e-3 apart.  The fp32 floor is that 2e-3 (it was 1e-3, which decoders.2.bn.beta_i sat at: 0.98e-3
-# before, 1.07e-3 after the time-Winograd forward); the per-tensor factor and the whole-vector factor are unchanged.
-YARD = {"fp32": (12.0, 2e-3, 3.0), "bf16x3": (15.0, 6e-3, 10.0)}
+# (per-tensor factor, per-tensor floor as a multiple of the REFERENCE's whole-vector deviation, whole-vector factor).
+# The yardstick is what the reference's own float32 arithmetic delivers on this step (an error model, not the last
+# measurement): its gradients (fixture grad_dccrn_full.npz) are 1.16e-3 from float64 as one vector, this path 1.38e-3 (fp32) -- the same
+# distance from the truth, median per-tensor ratio 1.08.  The float32 ORACLE alone is a poor yardstick (1.6e-4 on this step: its
+# evaluation order happens to flip few PReLU elements; it was the only yardstick before round 4).  PReLU-flip noise is an independent,
+# heavy-tailed sample in each float32 evaluation of a tensor, so:
+#   * whole vector, where it averages out: at most 2 x the worse of the two float32 yardsticks (fp32); bf16x3 rounds its forward to 1e-5
+#     instead of 1e-6, ten times the flips, sqrt(10) = 3.2 x the deviation (measured 3.8 x): factor 6;
+#   * per tensor: 6 x (10 x) the worse yardstick of THAT tensor, with a floor of 2 x (6 x) the reference's whole-vector deviation for
+#     tensors where both yardsticks happen to be flip-free (e.g. decoders.4: 4e-6).  Measured above the floor: ratio <= 3.2 (5.1).
+YARD = {"fp32": (6.0, 2.0, 2.0), "bf16x3": (10.0, 6.0, 6.0)}
 
 
 def ops_precision():
