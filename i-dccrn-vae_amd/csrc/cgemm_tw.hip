@@ -614,17 +614,22 @@ extern "C" int idv_ctconv2d_tw_fwd(const float* x0, int C0, const float* x1, int
     hipStream_t st = (hipStream_t)stream;
     a.stats = stats;
     if (stats && stats_work) { a.stats = stats_work; a.stats_rep = stats_rep; }       // replicated sums, folded afterwards (common.hpp)
-    static const int dbg = [] { const char* e = getenv("IDV_TW_DBG"); return e ? atoi(e) : 0; }();
-    static const int only = [] { const char* e = getenv("IDV_TW_ONLY"); return e ? atoi(e) : 0; }();      // 1 / 2: one phase only
     int rc = 0;
-    if (dbg && !stats) {                                      // timing experiments (wrong results): DBG bits of the kernel
+#ifdef IDV_TW_EXPERIMENTS
+    // timing experiments (WRONG results by construction; compiled in only with -DIDV_TW_EXPERIMENTS): IDV_TW_DBG = the kernel's DBG bits
+    // (1: no staging after the prologue, 2: no weight re-loads), IDV_TW_ONLY = 1 / 2: one phase only
+    static const int dbg = [] { const char* e = getenv("IDV_TW_DBG"); return e ? atoi(e) : 0; }();
+    static const int only = [] { const char* e = getenv("IDV_TW_ONLY"); return e ? atoi(e) : 0; }();
+    if (dbg && !stats) {
         if (only != 2) rc = dbg == 1 ? launch_tw_ph<0, 8, 1>(a, st) : (dbg == 2 ? launch_tw_ph<0, 8, 2>(a, st) : launch_tw_ph<0, 8, 3>(a, st));
         if (rc) return rc;
         if (only != 1) rc = dbg == 1 ? launch_tw_ph<1, 8, 1>(a, st) : (dbg == 2 ? launch_tw_ph<1, 8, 2>(a, st) : launch_tw_ph<1, 8, 3>(a, st));
         return rc;
     }
-    if (only != 2) rc = launch_tw_ph<0, 8>(a, st);
-    if (!rc && only != 1) rc = launch_tw_ph<1, 8>(a, st);
+    if (only) return only == 1 ? launch_tw_ph<0, 8>(a, st) : launch_tw_ph<1, 8>(a, st);
+#endif
+    rc = launch_tw_ph<0, 8>(a, st);
+    if (!rc) rc = launch_tw_ph<1, 8>(a, st);
     if (rc || !(stats && stats_work)) return rc;
     return idv_launch_stats_collapse(stats_work, stats_rep, Cout * 5, stats, st);
 }

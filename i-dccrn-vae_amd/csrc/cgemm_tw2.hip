@@ -544,16 +544,16 @@ extern "C" int idv_cconv2d_tw_fwd(const float* x0, int Cin, const float* wfrag, 
     hipStream_t st = (hipStream_t)stream;
     a.stats = stats;
     if (stats && stats_work) { a.stats = stats_work; a.stats_rep = stats_rep; }
-    static const int dbg = [] { const char* e = getenv("IDV_TW_DBG"); return e ? atoi(e) : 0; }();
     int rc;
+#ifdef IDV_TW_EXPERIMENTS
+    // timing experiments (WRONG results by construction; compiled in only with -DIDV_TW_EXPERIMENTS): IDV_TW_DBG = the kernel's DBG bits
+    static const int dbg = [] { const char* e = getenv("IDV_TW_DBG"); return e ? atoi(e) : 0; }();
+    if (!stats && dbg == 1) return tshift ? launch_tw2<true, false, 1>(a, st) : launch_tw2<false, false, 1>(a, st);
+    if (!stats && dbg == 2) return tshift ? launch_tw2<true, false, 2>(a, st) : launch_tw2<false, false, 2>(a, st);
+    if (!stats && dbg == 3) return tshift ? launch_tw2<true, false, 3>(a, st) : launch_tw2<false, false, 3>(a, st);
+#endif
     if (stats)
         rc = tshift ? launch_tw2<true, true, 0>(a, st) : launch_tw2<false, true, 0>(a, st);
-    else if (dbg == 1)
-        rc = tshift ? launch_tw2<true, false, 1>(a, st) : launch_tw2<false, false, 1>(a, st);
-    else if (dbg == 2)
-        rc = tshift ? launch_tw2<true, false, 2>(a, st) : launch_tw2<false, false, 2>(a, st);
-    else if (dbg == 3)
-        rc = tshift ? launch_tw2<true, false, 3>(a, st) : launch_tw2<false, false, 3>(a, st);
     else
         rc = tshift ? launch_tw2<true, false, 0>(a, st) : launch_tw2<false, false, 0>(a, st);
     if (rc || !(stats && stats_work)) return rc;
