@@ -164,6 +164,7 @@ def test_cconv_wino(ops, transposed, causal, cin, cout, F, T, B, skip_c, fold, s
     (True, 256, 64, 17, 70, 2, 0, True, 0.25),      # a real layer width (dec3's channels)
     (True, 16, 36, 4, 31, 3, 4, False, None),       # J = 96: not a multiple of 64; second source of 4 channels (ragged last chunk)
     (True, 16, 32, 9, 37, 2, 16, True, 0.25),       # ONE co tile (dec4's width: cgemm_wino does not serve it, cgemm_gauss is the reference)
+    (True, 8, 40, 6, 30, 3, 0, False, 0.2),         # ODD number of columns (B = 3, Tp = 31: J = 93): the last column pair is half empty
 ])
 def test_ctconv_time_winograd(ops, causal, cin, cout, F, T, B, skip_c, fold, slope):
     """The transposed conv with Winograd-transformed frequency AND time taps (csrc/cgemm_tw.hip: F(2,2) over pairs of output
@@ -195,7 +196,7 @@ def test_ctconv_time_winograd(ops, causal, cin, cout, F, T, B, skip_c, fold, slo
     (False, 64, 40, 17, 9, 2, False, None),         # non-causal taps (x[t], x[t+1])
     (True, 64, 48, 5, 700, 1, False, None),         # many column tiles, 3 output rows, odd Tp
     (True, 128, 128, 33, 70, 2, True, 0.25),        # a real layer width (enc3)
-    (True, 80, 32, 4, 30, 3, True, None),           # even input row count (Fout = 2: one tile), one co tile
+    (True, 80, 32, 4, 30, 3, True, None),           # even input row count (Fout = 2: one tile), one co tile; odd column count (J = 93)
 ])
 def test_cconv_time_winograd(ops, causal, cin, cout, F, T, B, fold, slope):
     """The conv with Winograd-transformed frequency AND time taps (csrc/cgemm_tw2.hip) against the oracle's four real convolutions and
