@@ -547,8 +547,14 @@ int launch_tw_ph_l(const TwArgs& a, hipStream_t st) {
     }
     if (nblk > 0x7fffffffLL) return IDV_EINVAL;
     auto k = cconv_tw_kernel<PH, CIK, LEFT, DBG, RDW, WVEC, STATS>;
-    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-        return IDV_ELAUNCH;
+    // (once per instantiation and device: setting it on every launch is host time, a lot of it under a profiler)
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return IDV_ELAUNCH;
+    if (smem > 64 * 1024 && !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return IDV_ELAUNCH;
+        attr_set[dev] = true;
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), smem, st, b);
     return idv_launch_status();
 }
