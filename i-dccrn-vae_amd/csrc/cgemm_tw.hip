@@ -13,10 +13,13 @@
 // Tiles.  One accumulator tile per (frequency product r, Gauss plane g, time product tau): the even-row phase (PH 0) has 4 x 3 x 3
 // = 36 tiles, the odd-row phase (PH 1) 3 x 3 x 3 = 27, for ONE tile of 32 complex output channels x 64 columns x one pair of input
 // rows.  No two tiles share an operand (each has its own transformed taps and its own transformed input row), so the tiles are
-// dealt to the four waves of a workgroup round-robin (tile t -> wave t % 4: 9 / 7 tiles per wave, 144 accumulator registers, two
-// workgroups per CU) and the output transforms (time, Gauss, frequency) run in the epilogue on tiles exchanged through the LDS.
-// Staging forms the transformed input rows once per element at the LDS write: frequency (A + cb B), Gauss (s = r + i), time
-// (a - b, b, b - d).  Weights: cgemm_wino's fragments re-ordered by idv_pack_cconv_tw (lane = channel parity x 32 + co).
+// dealt to the four waves of a workgroup (tw_tile: even rows wave = r with its nine planes; odd rows waves 0 .. 2 = r with planes
+// 0 .. 5 and 8, wave 3 the planes 6, 7 of all three r: 9 / 7 tiles per wave, two workgroups per CU) and the output transforms (time,
+// Gauss, frequency) run in the epilogue on tiles exchanged through the LDS.
+// Staging writes the RAW input rows, each as nine planes (s = r + i | r | i) x (a - b | b | b - d) of 32 column pairs, planes (2 p,
+// 2 p + 1) interleaved per pair (one 8-byte read fetches the operands of two tiles); the FREQUENCY transform A + cb B of cgemm_wino
+// happens at the operand read (two reads + one add).  Weights: cgemm_wino's fragments re-ordered by idv_pack_cconv_tw (lane =
+// channel parity x 32 + co), per (channel pair, wave).  Design notes and measurements: DESIGN.md 3.1e.
 #include <cstdint>
 #include <cstdlib>
 #include "cgemm.hpp"
